@@ -1,0 +1,142 @@
+/*
+ * stofnet_amd.h -- C ABI of the MI355X-native StofNet inference hot path.
+ *
+ * One shared library (libstofnet_amd.so, gfx950 code objects embedded) replaces
+ * the ATen calls that the reference's hot path makes (the reference has no native
+ * code of its own).  Every entry point cites the reference
+ * interface it stands in for (paths relative to hahnec/stofnet).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers are raw HIP device
+ *     addresses, `stream` is a hipStream_t passed as void*.
+ *   - ownership: the caller owns every buffer including workspaces; the library
+ *     allocates nothing per call and keeps no mutable global state.
+ *   - all device work is enqueued asynchronously on `stream`; no hidden syncs.
+ *   - every function returns a stof_status (0 = ok); nothing throws or aborts
+ *     across the ABI.  stof_status_string() gives a static message.
+ *   - activations are fp32, contiguous, NCL as in the reference.
+ */
+#ifndef STOFNET_AMD_H
+#define STOFNET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STOF_ABI_VERSION 1
+
+typedef enum stof_status {
+    STOF_OK = 0,
+    STOF_ERR_BAD_ARG = 1,         /* null pointer, negative size, ...                          */
+    STOF_ERR_ODD_SGB_REMAINDER = 2,/* L - 80*floor(L/80) is odd: the reference raises RuntimeError
+                                      at models/stofnet.py:115                       */
+    STOF_ERR_UNSUPPORTED = 3,     /* shape/mode outside what the kernels implement              */
+    STOF_ERR_WORKSPACE = 4,       /* workspace or packed-weight buffer too small                */
+    STOF_ERR_HIP = 5,             /* a HIP runtime call or launch failed                        */
+    STOF_ERR_CHANNELS = 6         /* channel count not divisible by r (view error in the reference,
+                                      utils/sample_shuffle.py:24)                                */
+} stof_status;
+
+const char* stof_status_string(int status);
+int stof_abi_version(void);
+
+/* ------------------------------------------------------------------------- *
+ * Network description (models/stofnet.py:11 ctor arguments that the shipped
+ * checkpoints use: num_features=64, num_blocks=13, kernel_sizes=[9,7,3],
+ * in_channels=1).
+ * ------------------------------------------------------------------------- */
+typedef struct stof_net_desc {
+    int32_t upsample_factor;     /* r: conv_last has r output channels (1..64)                  */
+    int32_t semi_global_scale;   /* 80 = SemiGlobalBlock present, 1 = ablation without it       */
+    int32_t precision;           /* STOF_PREC_*                                                 */
+    int32_t reserved;
+} stof_net_desc;
+
+#define STOF_PREC_FP32 0          /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), parity baseline     */
+#define STOF_PREC_F16X3 1         /* split-fp16 hi/lo operands, 3 MFMA passes, fp32 accumulate     */
+
+/* Parameter order for stof_pack_weights(): the reference's state_dict tensors
+ * (models/stofnet.py:23-31,88,94), each a host pointer to contiguous fp32:
+ *   [0] conv1.weight (64,1,9)      [1] conv1.bias (64)
+ *   [2+2i] conv{2+i}.weight (64,64,7), [3+2i] conv{2+i}.bias (64)   i = 0..10
+ *   [24] conv_last.weight (r,64,3) [25] conv_last.bias (r)
+ *   [26] semi_global_block.contract_conv.weight (512,64,5) [27] .bias (512)
+ *   [28] semi_global_block.expand_conv.weight (64,512,5)   [29] .bias (64)
+ * Entries 26..29 are ignored (may be NULL) when semi_global_scale == 1.      */
+#define STOF_NUM_PARAMS 30
+
+/* Bytes of the packed (kernel-layout) weight blob for `desc`. */
+size_t stof_packed_weights_bytes(const stof_net_desc* desc);
+
+/* One-time repack of the state_dict into the kernels' streaming layout.  Pure
+ * host function (no GPU needed): writes `stof_packed_weights_bytes()` bytes to
+ * `packed_host`; the caller uploads the blob to device memory once.
+ * Replaces: nn.Module.load_state_dict + .to(device) (main.py:169,176-177).   */
+int stof_pack_weights(const stof_net_desc* desc, const float* const* params,
+                      void* packed_host, size_t packed_bytes);
+
+/* Device workspace needed by stof_forward for a batch of N rows of length L. */
+size_t stof_forward_workspace_bytes(const stof_net_desc* desc, int64_t N, int64_t L);
+
+/* StofNet.forward (models/stofnet.py:42-67): x[N,1,L] -> y[N,1,L*r], both fp32
+ * device buffers.  `packed_dev` is the uploaded blob from stof_pack_weights.
+ * Returns STOF_ERR_ODD_SGB_REMAINDER for the lengths on which the reference's
+ * SemiGlobalBlock raises (Q1).                                               */
+int stof_forward(const stof_net_desc* desc, const void* packed_dev,
+                 const float* x, float* y, int64_t N, int64_t L,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* SampleShuffle1D.forward (utils/sample_shuffle.py:10-28):
+ * in[N, C_in, W] -> out[N, C_in/r, W*r], out[n,c,w*r+k] = in[n,k*C+c,w].     */
+int stof_sample_shuffle(const float* in, float* out, int64_t N, int64_t C_in,
+                        int64_t W, int32_t r, void* stream);
+
+/* get_maxima_positions (utils/mask2samples.py:26-34) per row of scores[N,1,M]:
+ * NMS window `window_size` (made odd, :7), then threshold mode (has_threshold
+ * != 0, the reference's `if threshold:`) or per-row arg-max mode.
+ *   counts[N]       : detections per row (int32)
+ *   idx[N, idx_cap] : time indices (int32, ascending) of the first idx_cap
+ *                     detections of each row; unwritten tail is left untouched
+ * The caller sizes idx_cap; a row with counts > idx_cap is truncated in `idx`
+ * only (counts is exact), so the caller can re-run with a larger cap.        */
+int stof_pick_maxima(const float* scores, int64_t N, int64_t M, int32_t window_size,
+                     int32_t has_threshold, float threshold,
+                     int32_t* counts, int32_t* idx, int64_t idx_cap, void* stream);
+
+/* Second half of mask2coords (utils/mask2samples.py:92-112): scatter the first
+ * kmax indices of each row into coords[N, kmax] (fp32, zero padded) and divide
+ * by upsample_factor.                                                        */
+int stof_indices_to_coords(const int32_t* counts, const int32_t* idx, int64_t idx_cap,
+                           int64_t N, int64_t kmax, float upsample_factor,
+                           float* coords, void* stream);
+
+/* hilbert_transform (utils/hilbert.py:5-21) along the last dim of x[N, n]:
+ * writes any of env[N,n] = |v|, re[N,n], im[N,n] that is non-NULL.           */
+size_t stof_hilbert_workspace_bytes(int64_t N, int64_t n);
+int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, float* re, float* im,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* grad_peak_detect (models/gradpeak.py:8-68) on an envelope env[N, L].
+ * Stage 1 computes the smoothed gradient (gradient spacing grad_step, Gaussian
+ * sigma (2*grad_step-1)/6, taps from `taps` [2*radius+1] prepared by the host
+ * exactly as models/gradpeak.py:71-76 does) into grad[N, L] and the batch sums
+ * stats[2] = (sum, sum of squares) in double for the default threshold (Q7).  */
+int stof_gradpeak_gradient(const float* env, int64_t N, int64_t L, int32_t grad_step,
+                           const float* taps, int32_t radius, float* grad, double* stats,
+                           void* stream);
+/* Stage 2: threshold crossings + pairing per row.  echoes[N, cap, 3] =
+ * (onset, peak, env[peak]) for the first `cap` echoes of each row, counts[N]
+ * exact; flags[0] is set to 1 if some row has edges but no surviving
+ * candidate (Q9: the reference then returns an empty tensor for the batch).  */
+int stof_gradpeak_pair(const float* env, const float* grad, int64_t N, int64_t L,
+                       float thres_pos, int32_t ival_min, int32_t ival_max,
+                       float* echoes, int64_t cap, int32_t* counts, int32_t* flags,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STOFNET_AMD_H */

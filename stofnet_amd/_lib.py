@@ -1,0 +1,114 @@
+"""ctypes binding of libstofnet_amd.so (the C ABI in include/stofnet_amd.h).
+
+There is no CPU or PyTorch fallback: if the HIP library is missing or a tensor is
+not on a ROCm device the call raises.  PyTorch is used only for device memory and
+streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libstofnet_amd.so')
+
+STOF_OK = 0
+STOF_ERR_BAD_ARG = 1
+STOF_ERR_ODD_SGB_REMAINDER = 2
+STOF_ERR_UNSUPPORTED = 3
+STOF_ERR_WORKSPACE = 4
+STOF_ERR_HIP = 5
+STOF_ERR_CHANNELS = 6
+
+PREC_FP32 = 0
+PREC_F16X3 = 1
+NUM_PARAMS = 30
+
+
+class NetDesc(ctypes.Structure):
+    _fields_ = [('upsample_factor', ctypes.c_int32), ('semi_global_scale', ctypes.c_int32),
+                ('precision', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+class StofnetLibraryMissing(ImportError):
+    pass
+
+
+_c = ctypes
+_SIGNATURES = {
+    'stof_status_string': (_c.c_char_p, [_c.c_int]),
+    'stof_abi_version': (_c.c_int, []),
+    'stof_packed_weights_bytes': (_c.c_size_t, [_c.POINTER(NetDesc)]),
+    'stof_pack_weights': (_c.c_int, [_c.POINTER(NetDesc), _c.POINTER(_c.c_void_p), _c.c_void_p, _c.c_size_t]),
+    'stof_forward_workspace_bytes': (_c.c_size_t, [_c.POINTER(NetDesc), _c.c_int64, _c.c_int64]),
+    'stof_forward': (_c.c_int, [_c.POINTER(NetDesc), _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
+                                _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    'stof_sample_shuffle': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32,
+                                       _c.c_void_p]),
+    'stof_pick_maxima': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_float,
+                                    _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
+    'stof_indices_to_coords': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float,
+                                          _c.c_void_p, _c.c_void_p]),
+    'stof_hilbert_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int64]),
+    'stof_hilbert': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    'stof_gradpeak_gradient': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32,
+                                          _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'stof_gradpeak_pair': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_int32,
+                                      _c.c_int32, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StofnetLibraryMissing(
+                f'{LIB_PATH} not found: build the HIP extension first (python -m stofnet_amd.build). '
+                'stofnet_amd has no CPU/PyTorch fallback.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def status_string(code: int) -> str:
+    return lib().stof_status_string(int(code)).decode()
+
+
+def check(code: int, what: str = ''):
+    """Convert a stof_status into the exception class the reference would raise."""
+    if code == STOF_OK:
+        return
+    msg = f'{what}: {status_string(code)}' if what else status_string(code)
+    if code in (STOF_ERR_ODD_SGB_REMAINDER, STOF_ERR_CHANNELS, STOF_ERR_HIP, STOF_ERR_WORKSPACE):
+        raise RuntimeError(msg)          # torch raises RuntimeError for shape mismatches
+    if code == STOF_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise ValueError(msg)
+
+
+def require_device(t: torch.Tensor, name: str = 'tensor') -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name} must be a torch.Tensor')
+    if t.device.type != 'cuda':
+        raise RuntimeError(f'{name} is on {t.device}: stofnet_amd runs on a ROCm device only '
+                           '(no CPU fallback; use oracle/ for a CPU check)')
+    return t
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,240 @@
+// hilbert_transform (utils/hilbert.py:5-21): v = ifft(H .* fft(y)) along the last dim with
+//   H = [1, 2 (bins 1..n/2-1), 1 (bin n/2), 0 ...]            (Q6: for odd n bin n/2 is not doubled)
+//
+// One work-group per row; the row lives in LDS as complex fp32 for its whole life:
+//   forward  : in-place decimation-in-frequency, mixed radix (4, 2, 3, 5, then any prime)
+//              -> spectrum in digit-reversed positions
+//   filter   : H[k]/n applied at each position's true frequency k
+//   inverse  : in-place decimation-in-time with the radices in reverse order, consuming the
+//              digit-reversed spectrum -> natural order, so no permutation pass exists.
+// Twiddles exp(-2 pi i k/n) come from a per-call table in the workspace (double-precision
+// sincospi, rounded once).  Prime radices > 5 run as out-of-place O(R) sums per output
+// through a second LDS buffer.
+#include <hip/hip_runtime.h>
+#include "stof_common.h"
+
+namespace {
+
+constexpr int MAX_STAGES = 24;
+constexpr int LDS_BYTES = 160 * 1024;
+
+struct FftPlan {
+    int n;
+    int nstages;
+    int radix[MAX_STAGES];
+    int needs_second;     // a prime radix > 5 is present
+};
+
+__host__ void make_plan(int n, FftPlan* p) {
+    p->n = n;
+    p->nstages = 0;
+    p->needs_second = 0;
+    int m = n;
+    while (m % 4 == 0) { p->radix[p->nstages++] = 4; m /= 4; }
+    while (m % 2 == 0) { p->radix[p->nstages++] = 2; m /= 2; }
+    while (m % 3 == 0) { p->radix[p->nstages++] = 3; m /= 3; }
+    while (m % 5 == 0) { p->radix[p->nstages++] = 5; m /= 5; }
+    for (int f = 7; (long long)f * f <= m; f += 2)
+        while (m % f == 0) { p->radix[p->nstages++] = f; m /= f; p->needs_second = 1; }
+    if (m > 1) { p->radix[p->nstages++] = m; p->needs_second = 1; }
+}
+
+__global__ void twiddle_kernel(float2* __restrict__ tw, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double s, c;
+    sincospi(-2.0 * (double)k / (double)n, &s, &c);
+    tw[k] = make_float2((float)c, (float)s);
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {   // a * conj(b)
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// y_q = sum_k x_k w^{qk}, w = exp(-+2 pi i/R); INV selects the conjugate root.
+template <int R, bool INV>
+__device__ __forceinline__ void small_dft(float2 (&x)[R], const float2* __restrict__ tw, int n) {
+    if constexpr (R == 2) {
+        const float2 a = x[0], b = x[1];
+        x[0] = cadd(a, b);
+        x[1] = csub(a, b);
+    } else if constexpr (R == 4) {
+        const float2 s02 = cadd(x[0], x[2]), d02 = csub(x[0], x[2]);
+        const float2 s13 = cadd(x[1], x[3]), d13 = csub(x[1], x[3]);
+        // forward: w = -i  -> (-i) * d13 = (d13.y, -d13.x); inverse: w = +i -> (-d13.y, d13.x)
+        const float2 rot = INV ? make_float2(-d13.y, d13.x) : make_float2(d13.y, -d13.x);
+        x[0] = cadd(s02, s13);
+        x[1] = cadd(d02, rot);
+        x[2] = csub(s02, s13);
+        x[3] = csub(d02, rot);
+    } else {
+        float2 w[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) w[k] = tw[(size_t)k * (n / R)];
+        float2 y[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            float2 acc = x[0];
+#pragma unroll
+            for (int k = 1; k < R; ++k) {
+                const float2 ww = w[(q * k) % R];
+                acc = cadd(acc, INV ? cmulc(x[k], ww) : cmul(x[k], ww));
+            }
+            y[q] = acc;
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) x[q] = y[q];
+    }
+}
+
+// One in-place stage over the whole row.  m = current block length, sub = m / R.
+template <int R, bool INV>
+__device__ void stage_small(float2* __restrict__ d, const float2* __restrict__ tw, int n, int m) {
+    const int sub = m / R;
+    const int tstep = n / m;
+    for (int b = threadIdx.x; b < n / R; b += blockDim.x) {
+        const int blk = b / sub, j = b - blk * sub;
+        float2* base = d + blk * m + j;
+        float2 x[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) x[k] = base[k * sub];
+        if (INV) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) x[q] = cmulc(x[q], tw[(size_t)j * q * tstep]);
+        }
+        small_dft<R, INV>(x, tw, n);
+        if (!INV) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) x[q] = cmul(x[q], tw[(size_t)j * q * tstep]);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) base[k * sub] = x[k];
+    }
+}
+
+// Prime radix R > 5: out-of-place, one output element per thread iteration.
+template <bool INV>
+__device__ void stage_generic(const float2* __restrict__ src, float2* __restrict__ dst,
+                              const float2* __restrict__ tw, int n, int m, int R) {
+    const int sub = m / R;
+    const int tstep = n / m;
+    const int rstep = n / R;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int blk = e / m, rem = e - blk * m;
+        const int q = rem / sub, j = rem - q * sub;
+        const float2* base = src + blk * m + j;
+        float2 acc = make_float2(0.f, 0.f);
+        int idx = 0;                                  // (q*k) mod R
+        for (int k = 0; k < R; ++k) {
+            float2 v = base[k * sub];
+            if (INV) v = cmulc(v, tw[(size_t)j * k * tstep]);      // input twiddle (k plays q's role)
+            const float2 w = tw[(size_t)idx * rstep];
+            acc = cadd(acc, INV ? cmulc(v, w) : cmul(v, w));
+            idx += q;
+            if (idx >= R) idx -= R;
+        }
+        if (!INV) acc = cmul(acc, tw[(size_t)j * q * tstep]);
+        dst[e] = acc;
+    }
+}
+
+template <bool INV>
+__device__ void run_stage(float2*& cur, float2*& other, const float2* tw, int n, int m, int R) {
+    switch (R) {
+        case 2: stage_small<2, INV>(cur, tw, n, m); break;
+        case 3: stage_small<3, INV>(cur, tw, n, m); break;
+        case 4: stage_small<4, INV>(cur, tw, n, m); break;
+        case 5: stage_small<5, INV>(cur, tw, n, m); break;
+        default: {
+            stage_generic<INV>(cur, other, tw, n, m, R);
+            float2* t = cur; cur = other; other = t;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void hilbert_kernel(const float* __restrict__ x, const float2* __restrict__ tw,
+                                                      const FftPlan plan, float* __restrict__ env,
+                                                      float* __restrict__ re, float* __restrict__ im) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int n = plan.n;
+    float2* cur = lds;
+    float2* other = lds + n;
+    const size_t row = blockIdx.x;
+    const float* xr = x + row * (size_t)n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) cur[i] = make_float2(xr[i], 0.f);
+    __syncthreads();
+
+    // forward DIF: block length shrinks n -> 1
+    int m = n;
+    for (int s = 0; s < plan.nstages; ++s) {
+        run_stage<false>(cur, other, tw, n, m, plan.radix[s]);
+        m /= plan.radix[s];
+    }
+    // filter at the true frequency of each (digit-reversed) position, fold in the 1/n of ifft
+    const float inv_n = 1.0f / (float)n;
+    const int nyq = n / 2;
+    for (int p = threadIdx.x; p < n; p += blockDim.x) {
+        int rem = p, mm = n, k = 0, mult = 1;
+        for (int s = 0; s < plan.nstages; ++s) {
+            const int R = plan.radix[s];
+            mm /= R;
+            const int q = rem / mm;
+            rem -= q * mm;
+            k += q * mult;
+            mult *= R;
+        }
+        const float h = (k == 0 || k == nyq) ? 1.f : (k < nyq ? 2.f : 0.f);
+        const float sc = h * inv_n;
+        float2 v = cur[p];
+        cur[p] = make_float2(v.x * sc, v.y * sc);
+    }
+    __syncthreads();
+    // inverse DIT: stages in reverse order, block length grows 1 -> n
+    for (int s = plan.nstages - 1; s >= 0; --s) {
+        m *= plan.radix[s];
+        run_stage<true>(cur, other, tw, n, m, plan.radix[s]);
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float2 v = cur[i];
+        if (env) env[row * (size_t)n + i] = hypotf(v.x, v.y);
+        if (re) re[row * (size_t)n + i] = v.x;
+        if (im) im[row * (size_t)n + i] = v.y;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t stof_hilbert_workspace_bytes(int64_t N, int64_t n) {
+    (void)N;
+    return n > 0 ? (size_t)n * sizeof(float2) + 256 : 0;
+}
+
+extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, float* re, float* im,
+                            void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!x || N < 0 || n < 0 || (!env && !re && !im)) return STOF_ERR_BAD_ARG;
+    if (N == 0 || n == 0) return STOF_OK;
+    if (!workspace || workspace_bytes < stof_hilbert_workspace_bytes(N, n)) return STOF_ERR_WORKSPACE;
+    if (N > 0x7fffffffLL || n > LDS_BYTES / 8) return STOF_ERR_UNSUPPORTED;
+    FftPlan plan;
+    make_plan((int)n, &plan);
+    const size_t lds = (size_t)n * sizeof(float2) * (plan.needs_second ? 2 : 1);
+    if (lds > (size_t)LDS_BYTES) return STOF_ERR_UNSUPPORTED;      // prime factor > 5 and n > 10240
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hilbert_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return STOF_ERR_HIP;
+        attr_done = true;
+    }
+    float2* tw = static_cast<float2*>(workspace);
+    hipLaunchKernelGGL(twiddle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, (int)n);
+    hipLaunchKernelGGL(hilbert_kernel, dim3((unsigned)N), dim3(512), lds, stream, x, tw, plan, env, re, im);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}

@@ -1,0 +1,121 @@
+// Host-side repack of the reference's state_dict (models/stofnet.py:23-31,88,94) into
+// the streaming layout the gfx950 kernels read.  Pure CPU code: no HIP calls.
+#include <string.h>
+#include "stof_common.h"
+
+using namespace stof;
+
+static void layout(const stof_net_desc* d, PackedHeader* h) {
+    memset(h, 0, sizeof(*h));
+    h->magic = PACK_MAGIC;
+    h->abi = STOF_ABI_VERSION;
+    h->r = d->upsample_factor;
+    h->sgs = d->semi_global_scale;
+    h->precision = d->precision;
+    uint64_t off = sizeof(PackedHeader) / sizeof(float);
+    h->off_c1 = off;      off += 64 * 10;
+    h->off_bias = off;    off += 13 * 64;
+    h->off_body = off;    off += (uint64_t)BODY_NCHUNK * BODY_CHUNK_F;
+    if (d->semi_global_scale != 1) {
+        h->off_cbias = off;   off += NF_SGB;
+        h->off_cchunks = off; off += (uint64_t)SGB_NCHUNK * SGB_CHUNK_F;
+        h->off_ew = off;      off += 5ull * NF_SGB * NF;
+        h->off_ebias = off;   off += NF;
+    }
+    h->total_floats = off;
+}
+
+static int check_desc(const stof_net_desc* d) {
+    if (!d) return STOF_ERR_BAD_ARG;
+    if (d->upsample_factor < 1 || d->upsample_factor > 64) return STOF_ERR_UNSUPPORTED;
+    if (d->semi_global_scale != 1 && d->semi_global_scale != SGB_SCALE) return STOF_ERR_UNSUPPORTED;
+    if (d->precision != STOF_PREC_FP32) return STOF_ERR_UNSUPPORTED;
+    return STOF_OK;
+}
+
+extern "C" size_t stof_packed_weights_bytes(const stof_net_desc* desc) {
+    if (check_desc(desc) != STOF_OK) return 0;
+    PackedHeader h;
+    layout(desc, &h);
+    return (size_t)h.total_floats * sizeof(float);
+}
+
+extern "C" int stof_pack_weights(const stof_net_desc* desc, const float* const* params,
+                                 void* packed_host, size_t packed_bytes) {
+    int st = check_desc(desc);
+    if (st != STOF_OK) return st;
+    if (!params || !packed_host) return STOF_ERR_BAD_ARG;
+    const int nparams = desc->semi_global_scale != 1 ? STOF_NUM_PARAMS : 26;
+    for (int i = 0; i < nparams; ++i)
+        if (!params[i]) return STOF_ERR_BAD_ARG;
+    PackedHeader h;
+    layout(desc, &h);
+    if (packed_bytes < (size_t)h.total_floats * sizeof(float)) return STOF_ERR_WORKSPACE;
+    memset(packed_host, 0, (size_t)h.total_floats * sizeof(float));
+    memcpy(packed_host, &h, sizeof(h));
+    float* base = static_cast<float*>(packed_host);
+    const int r = desc->upsample_factor;
+
+    // conv1: [ch][tap 0..8, bias]
+    for (int c = 0; c < NF; ++c) {
+        for (int t = 0; t < 9; ++t) base[h.off_c1 + c * 10 + t] = params[0][c * 9 + t];
+        base[h.off_c1 + c * 10 + 9] = params[1][c];
+    }
+    // biases of sweep layers 1..11 (conv2..conv12) and 12 (conv_last, zero padded)
+    for (int j = 1; j <= 11; ++j)
+        for (int c = 0; c < NF; ++c) base[h.off_bias + j * 64 + c] = params[3 + 2 * (j - 1)][c];
+    for (int c = 0; c < r; ++c) base[h.off_bias + 12 * 64 + c] = params[25][c];
+
+    // body chunks in streaming order: layer, tap, half -> [64 out][32 in (+4 pad)]
+    float* ck = base + h.off_body;
+    for (int j = 1; j <= 12; ++j) {
+        const bool last = (j == 12);
+        const float* w = last ? params[24] : params[2 + 2 * (j - 1)];   // (co, 64, K)
+        const int K = last ? 3 : 7;
+        const int co = last ? r : NF;
+        for (int t = 0; t < K; ++t)
+            for (int hh = 0; hh < 2; ++hh) {
+                for (int m = 0; m < co; ++m)
+                    for (int cl = 0; cl < 32; ++cl)
+                        ck[m * WROWF + cl] = w[(m * NF + 32 * hh + cl) * K + t];
+                ck += BODY_CHUNK_F;
+            }
+    }
+    if (desc->semi_global_scale != 1) {
+        for (int c = 0; c < NF_SGB; ++c) base[h.off_cbias + c] = params[27][c];
+        const float* wc = params[26];                                   // (512, 64, 5)
+        float* cc = base + h.off_cchunks;
+        for (int ocb = 0; ocb < 4; ++ocb)
+            for (int t = 0; t < 5; ++t)
+                for (int hh = 0; hh < 2; ++hh) {
+                    for (int o = 0; o < 128; ++o)
+                        for (int cl = 0; cl < 32; ++cl)
+                            cc[o * WROWF + cl] = wc[((128 * ocb + o) * NF + 32 * hh + cl) * 5 + t];
+                    cc += SGB_CHUNK_F;
+                }
+        const float* we = params[28];                                   // (64, 512, 5)
+        for (int t = 0; t < 5; ++t)
+            for (int c = 0; c < NF_SGB; ++c)
+                for (int o = 0; o < NF; ++o)
+                    base[h.off_ew + ((uint64_t)t * NF_SGB + c) * NF + o] = we[(o * NF_SGB + c) * 5 + t];
+        for (int o = 0; o < NF; ++o) base[h.off_ebias + o] = params[29][o];
+    }
+    return STOF_OK;
+}
+
+extern "C" const char* stof_status_string(int status) {
+    switch (status) {
+        case STOF_OK: return "ok";
+        case STOF_ERR_BAD_ARG: return "bad argument (null pointer or negative size)";
+        case STOF_ERR_ODD_SGB_REMAINDER:
+            return "The size of tensor a must match the size of tensor b at non-singleton dimension 2 "
+                   "(SemiGlobalBlock: L - 80*floor(L/80) is odd)";
+        case STOF_ERR_UNSUPPORTED: return "unsupported shape or mode";
+        case STOF_ERR_WORKSPACE: return "workspace or packed-weight buffer too small";
+        case STOF_ERR_HIP: return "HIP runtime error";
+        case STOF_ERR_CHANNELS: return "input channels not divisible by upsample_factor";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int stof_abi_version(void) { return STOF_ABI_VERSION; }

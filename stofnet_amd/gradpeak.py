@@ -1,0 +1,105 @@
+"""GradPeak / toa_detect / grad_peak_detect on the gfx950 kernels
+(mirrors models/gradpeak.py:8-133)."""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hilbert import hilbert_envelope
+
+_CAP = 32          # echoes per row kept by the first pass; rows with more trigger a re-run
+
+
+def gaussian_kernel_1d(sigma: float, num_sigmas: float = 3.) -> torch.Tensor:
+    """models/gradpeak.py:71-76.  float64 taps; sigma enters as float32 exactly as
+    torch.distributions.Normal(loc=0, scale=sigma) holds it."""
+    if not sigma > 0:
+        raise ValueError(f'Expected parameter scale of distribution Normal to be > 0, but found {sigma}')
+    radius = int(num_sigmas * sigma) + 1
+    support = np.arange(-radius, radius + 1, dtype=np.float64)
+    s32 = np.float32(sigma)
+    var = np.float64(np.float32(s32 * s32))
+    log_scale = np.float64(np.log(s32, dtype=np.float32))
+    k = np.exp(-(support ** 2) / (2.0 * var) - log_scale - math.log(math.sqrt(2.0 * math.pi)))
+    return torch.from_numpy(k * (1.0 / k.sum()))
+
+
+def grad_peak_detect(data, grad_step: int = None, threshold: float = None, ival_smin: int = None,
+                     ival_smax: int = None):
+    """models/gradpeak.py:8-68 -> [N, Kmax, 3] = (onset, peak, amplitude), zero padded."""
+    _lib.require_device(data, 'data')
+    env = data.detach().contiguous().float()
+    n, L = env.shape
+    grad_step = grad_step if grad_step is not None else 2
+    taps64 = gaussian_kernel_1d((grad_step * 2 - 1) / 6)
+    taps = taps64.to(env.device, torch.float32)
+    radius = (taps.numel() - 1) // 2
+    lib = _lib.lib()
+    grad = torch.empty_like(env)
+    stats = torch.zeros(2, dtype=torch.float64, device=env.device)
+    stream = _lib.stream_ptr(env.device)
+    with torch.cuda.device(env.device):
+        _lib.check(lib.stof_gradpeak_gradient(_lib.ptr(env), n, L, int(grad_step), _lib.ptr(taps), radius,
+                                              _lib.ptr(grad), _lib.ptr(stats), stream), 'stof_gradpeak_gradient')
+    if threshold is not None:
+        thres_pos = float(threshold)
+    else:
+        # Q7: (unbiased std of the WHOLE batch tensor) ** 16 * 1.2e13, in float32 (models/gradpeak.py:18)
+        s1, s2 = (float(v) for v in stats.cpu())
+        cnt = n * L
+        var = max(s2 - s1 * s1 / cnt, 0.0) / max(cnt - 1, 1)
+        std = np.float32(math.sqrt(var))
+        with np.errstate(over='ignore', under='ignore'):
+            thres_pos = float(np.float32(np.float32(std ** np.float32(16)) * np.float32(1.2e13)))
+    if ival_smin is not None and ival_smax is not None:
+        ival = (int(ival_smin), int(ival_smax))
+    else:
+        ival = (grad_step // 2, grad_step * 3)
+
+    def run(cap):
+        echoes = torch.zeros((n, cap, 3), dtype=torch.float32, device=env.device)
+        counts = torch.empty((n,), dtype=torch.int32, device=env.device)
+        flags = torch.zeros((1,), dtype=torch.int32, device=env.device)
+        with torch.cuda.device(env.device):
+            _lib.check(lib.stof_gradpeak_pair(_lib.ptr(env), _lib.ptr(grad), n, L, thres_pos, ival[0], ival[1],
+                                              _lib.ptr(echoes), cap, _lib.ptr(counts), _lib.ptr(flags), stream),
+                       'stof_gradpeak_pair')
+        return echoes, counts, flags
+
+    echoes, counts, flags = run(_CAP)
+    kmax = int(counts.max()) if n else 0
+    if int(flags[0]):
+        # Q9 (models/gradpeak.py:54-55): the reference returns an empty [3, 0] tensor for the whole batch
+        return torch.tensor([[], [], []])
+    if kmax > _CAP:
+        echoes, counts, flags = run(kmax)
+    if kmax == 0:
+        return torch.zeros((n, 0), dtype=env.dtype, device=env.device)   # shape the reference builds (:66)
+    return echoes[:, :kmax].to(data.dtype)
+
+
+def toa_detect(frame, threshold=None, rescale_factor=1, echo_max=float('inf')):
+    """models/gradpeak.py:99-116."""
+    hilbert_data = hilbert_envelope(frame)
+    echoes = grad_peak_detect(hilbert_data, grad_step=rescale_factor // 6 * 5, ival_smin=rescale_factor,
+                              ival_smax=50 * rescale_factor, threshold=threshold)
+    echo_num = echoes.shape[1]
+    if echo_num > echo_max:
+        idcs = torch.argsort(echoes[..., -1], descending=True, dim=1)
+        echoes = torch.gather(echoes, dim=1, index=idcs[..., None].repeat(1, 1, 3))[:, :echo_max]
+        idcs = torch.argsort(echoes[..., 1], descending=False, dim=1)
+        echoes = torch.gather(echoes, dim=1, index=idcs[..., None].repeat(1, 1, 3))
+    return echoes
+
+
+class GradPeak(torch.nn.Module):
+    def __init__(self, threshold=None, rescale_factor=1, echo_max=float('inf'), onset_opt=False):
+        super().__init__()
+        self.threshold = threshold
+        self.onset_opt = onset_opt
+        self._fun = lambda x: toa_detect(x, threshold=threshold, rescale_factor=rescale_factor, echo_max=echo_max)
+
+    def forward(self, x):
+        echoes = self._fun(x.squeeze(1))
+        return echoes[..., 1] if not self.onset_opt else echoes[..., 0]

@@ -1,0 +1,45 @@
+"""hilbert_transform / HilbertTransform on the gfx950 LDS-FFT kernel
+(mirrors utils/hilbert.py:5-34)."""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _run(y: torch.Tensor, want_env: bool, want_complex: bool):
+    _lib.require_device(y, 'y')
+    n = y.shape[-1]
+    rows = y.numel() // max(n, 1)
+    yc = y.detach().contiguous().float().reshape(rows, n)
+    lib = _lib.lib()
+    ws = torch.empty(max(lib.stof_hilbert_workspace_bytes(rows, n), 16), dtype=torch.uint8, device=y.device)
+    env = torch.empty_like(yc) if want_env else None
+    re = torch.empty_like(yc) if want_complex else None
+    im = torch.empty_like(yc) if want_complex else None
+    with torch.cuda.device(y.device):
+        _lib.check(lib.stof_hilbert(_lib.ptr(yc), rows, n, _lib.ptr(env), _lib.ptr(re), _lib.ptr(im),
+                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(y.device)), 'stof_hilbert')
+    return env, re, im
+
+
+def hilbert_transform(y):
+    """Analytic signal (complex64) along the last dim, with the reference's bin rule (Q6)."""
+    _, re, im = _run(y, False, True)
+    return torch.complex(re, im).reshape(y.shape)
+
+
+def hilbert_envelope(y):
+    """abs(hilbert_transform(y)) without materialising the complex signal."""
+    env, _, _ = _run(y, True, False)
+    return env.reshape(y.shape)
+
+
+class HilbertTransform(nn.Module):
+    def __init__(self, concat_oscil=False):
+        super().__init__()
+        self.concat_oscil = concat_oscil
+
+    def forward(self, x):
+        if self.concat_oscil:
+            return torch.cat([hilbert_envelope(x), x], dim=1)
+        return hilbert_envelope(x)

@@ -1,0 +1,29 @@
+"""SampleShuffle1D on the gfx950 kernel (mirrors utils/sample_shuffle.py:6-28)."""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def sample_shuffle(x: torch.Tensor, upsample_factor: int) -> torch.Tensor:
+    _lib.require_device(x, 'x')
+    n, cin, w = x.shape
+    r = int(upsample_factor)
+    if cin % r != 0:
+        # the reference's .view raises RuntimeError (utils/sample_shuffle.py:24)
+        raise RuntimeError(f"shape '[{n}, {r}, {cin // r}, {w}]' is invalid for input of size {x.numel()}")
+    xc = x.contiguous().float()
+    out = torch.empty((n, cin // r, w * r), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().stof_sample_shuffle(_lib.ptr(xc), _lib.ptr(out), n, cin, w, r,
+                                                  _lib.stream_ptr(x.device)), 'stof_sample_shuffle')
+    return out.to(x.dtype)
+
+
+class SampleShuffle1D(nn.Module):
+    def __init__(self, upsample_factor):
+        super().__init__()
+        self.upsample_factor = upsample_factor
+
+    def forward(self, x):
+        return sample_shuffle(x, self.upsample_factor)

@@ -1,0 +1,150 @@
+"""StofNet with the reference's constructor, parameter names and forward signature
+(models/stofnet.py:9-117), executing on the gfx950 kernels through the C ABI.
+
+The module owns ordinary nn.Conv1d parameter holders so that the shipped
+checkpoints load with `load_state_dict(strict=True)` (main.py:176-177) and
+`model.parameters()` / `.to(device)` / `.eval()` behave as in the reference.
+`forward` never calls those convs: it repacks the parameters once into the
+kernels' streaming layout (re-done when a parameter changes) and calls
+`stof_forward`.  Inference only: the result carries no autograd graph.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+from . import _lib
+from .sample_shuffle import SampleShuffle1D
+
+_PRECISIONS = {'fp32': _lib.PREC_FP32, 'f16x3': _lib.PREC_F16X3}
+
+
+class SemiGlobalBlock(nn.Module):
+    """Parameter holder mirroring models/stofnet.py:80-96 (same attribute names)."""
+
+    def __init__(self, in_channels, out_channels, sample_scale=2, kernel_size=5):
+        super().__init__()
+        self.sample_scale = sample_scale
+        self.feat_scale = max(1, sample_scale // 10)
+        self.contract_conv = nn.Conv1d(in_channels, self.feat_scale * out_channels, kernel_size=kernel_size,
+                                       stride=1, padding=kernel_size // 2)
+        self.contract_relu = nn.LeakyReLU()
+        self.contract_pool = nn.MaxPool1d(kernel_size=sample_scale, stride=sample_scale)
+        self.expand_conv = nn.Conv1d(self.feat_scale * out_channels, out_channels, kernel_size=kernel_size,
+                                     stride=1, padding=kernel_size // 2)
+        self.expand_relu = nn.LeakyReLU()
+        self.expand_upsample = nn.Upsample(scale_factor=sample_scale, mode='nearest')
+
+    def forward(self, x):
+        raise RuntimeError('SemiGlobalBlock is fused into the StofNet kernels; call StofNet.forward')
+
+
+class StofNet(nn.Module):
+
+    def __init__(self, upsample_factor=4, num_features=64, num_blocks=13, kernel_sizes=[9, 7, 3], in_channels=1,
+                 semi_global_scale=80, weights_init=False, precision='fp32'):
+        super().__init__()
+        self.num_blocks = num_blocks
+        self.in_channels = in_channels
+        self.num_features = num_features
+        self.kernel_sizes = kernel_sizes
+        self.upsample_factor = upsample_factor
+        self.semi_global_scale = semi_global_scale
+        if precision not in _PRECISIONS:
+            raise ValueError(f'precision must be one of {sorted(_PRECISIONS)}')
+        self.precision = precision
+
+        self.conv1 = nn.Conv1d(in_channels, num_features, kernel_sizes[0], 1, 4)
+        self.conv_last = nn.Conv1d(num_features, upsample_factor, kernel_sizes[-1], 1, 1)
+        self.semi_global_block = (SemiGlobalBlock(num_features, num_features, semi_global_scale)
+                                  if semi_global_scale != 1 else None)
+        for i in range(2, num_blocks):
+            setattr(self, f'conv{i}', nn.Conv1d(num_features, num_features, kernel_sizes[1], 1, padding='same'))
+        self.sample_shuffle = SampleShuffle1D(upsample_factor)
+        self.residual_layers = list(range(3, num_blocks - 1, 2)) + [num_blocks - 1, num_blocks]
+        if weights_init:
+            self._initialize_weights()
+        self._packed = None
+        self._packed_key = None
+        self._workspace = None
+
+    # ---- kernel-side state -------------------------------------------------
+    def _supported(self):
+        return (self.num_features == 64 and self.num_blocks == 13 and list(self.kernel_sizes) == [9, 7, 3]
+                and self.in_channels == 1 and self.semi_global_scale in (1, 80)
+                and 1 <= self.upsample_factor <= 64)
+
+    def _param_list(self):
+        ps = [self.conv1.weight, self.conv1.bias]
+        for i in range(2, 13):
+            c = getattr(self, f'conv{i}')
+            ps += [c.weight, c.bias]
+        ps += [self.conv_last.weight, self.conv_last.bias]
+        if self.semi_global_block is not None:
+            ps += [self.semi_global_block.contract_conv.weight, self.semi_global_block.contract_conv.bias,
+                   self.semi_global_block.expand_conv.weight, self.semi_global_block.expand_conv.bias]
+        return ps
+
+    def _desc(self):
+        return _lib.NetDesc(int(self.upsample_factor), int(self.semi_global_scale), _PRECISIONS[self.precision], 0)
+
+    def _packed_weights(self, device):
+        ps = self._param_list()
+        key = (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in ps)
+        if self._packed is None or self._packed_key != key:
+            lib = _lib.lib()
+            desc = self._desc()
+            nbytes = lib.stof_packed_weights_bytes(ctypes.byref(desc))
+            if nbytes == 0:
+                raise NotImplementedError('this StofNet configuration is not supported by the gfx950 kernels')
+            host = [np.ascontiguousarray(p.detach().to('cpu', torch.float32).numpy()) for p in ps]
+            arr = (ctypes.c_void_p * _lib.NUM_PARAMS)()
+            for i, h in enumerate(host):
+                arr[i] = h.ctypes.data
+            blob = np.empty(nbytes, dtype=np.uint8)
+            _lib.check(lib.stof_pack_weights(ctypes.byref(desc), arr, blob.ctypes.data, nbytes), 'stof_pack_weights')
+            self._packed = torch.from_numpy(blob).to(device)
+            self._packed_key = key
+        return self._packed
+
+    # ---- forward -------------------------------------------------------------
+    def forward(self, x):
+        if not self._supported():
+            raise NotImplementedError('only the shipped StofNet architecture (64 features, 13 blocks, kernels '
+                                      '[9,7,3], 1 input channel, semi_global_scale in {1,80}) has gfx950 kernels')
+        _lib.require_device(x, 'x')
+        if x.dim() != 3 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f'expected input [N, {self.in_channels}, L], got {list(x.shape)}')
+        n, _, L = x.shape
+        r = int(self.upsample_factor)
+        xc = x.detach().contiguous().float()
+        y = torch.empty((n, 1, L * r), dtype=torch.float32, device=x.device)
+        lib = _lib.lib()
+        desc = self._desc()
+        packed = self._packed_weights(x.device)
+        ws_bytes = lib.stof_forward_workspace_bytes(ctypes.byref(desc), n, L)
+        if self._workspace is None or self._workspace.numel() < ws_bytes or self._workspace.device != x.device:
+            self._workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            code = lib.stof_forward(ctypes.byref(desc), _lib.ptr(packed), _lib.ptr(xc), _lib.ptr(y), n, L,
+                                    _lib.ptr(self._workspace), self._workspace.numel(), _lib.stream_ptr(x.device))
+        if code == _lib.STOF_ERR_ODD_SGB_REMAINDER:
+            # same failure as models/stofnet.py:115
+            got = L // 80 * 80 + 2 * ((L - L // 80 * 80) // 2)
+            raise RuntimeError(f'The size of tensor a ({L}) must match the size of tensor b ({got}) at '
+                               f'non-singleton dimension 2')
+        _lib.check(code, 'stof_forward')
+        return y
+
+    def _initialize_weights(self):
+        """models/stofnet.py:69-77."""
+        for i in range(1, self.num_blocks):
+            if i not in self.residual_layers:
+                init.orthogonal_(getattr(self, f'conv{i}').weight, init.calculate_gain('relu'))
+            else:
+                init.orthogonal_(getattr(self, f'conv{i}').weight)
+        init.orthogonal_(self.conv_last.weight)

@@ -1,0 +1,125 @@
+"""CPU checks of the C-ABI library: it loads, exports every symbol the header
+declares, and the pure-host weight packer lays the state_dict out as documented."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_weights
+from oracle import synth
+from stofnet_amd import _lib
+from stofnet_amd import build as sbuild
+
+
+@pytest.fixture(scope='module')
+def lib():
+    sbuild.build(verbose=False)
+    return _lib.lib()
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'stofnet_amd.h')).read()
+    declared = set(re.findall(r'^(?:int|size_t|const char\*)\s+(stof_[a-z0-9_]+)\s*\(', hdr, flags=re.M))
+    assert declared, 'no declarations found'
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f'{sym} declared in include/stofnet_amd.h but not exported'
+    assert set(_lib.EXPORTED_SYMBOLS) == declared
+    assert lib.stof_abi_version() == 1
+    assert _lib.status_string(0) == 'ok'
+    assert 'must match the size of tensor b' in _lib.status_string(_lib.STOF_ERR_ODD_SGB_REMAINDER)
+
+
+ORDER = (['conv1'] + [f'conv{i}' for i in range(2, 13)] + ['conv_last',
+         'semi_global_block.contract_conv', 'semi_global_block.expand_conv'])
+
+
+def pack(lib, sd, r, sgs):
+    desc = _lib.NetDesc(r, sgs, 0, 0)
+    n = lib.stof_packed_weights_bytes(ctypes.byref(desc))
+    arr = (ctypes.c_void_p * 30)()
+    keep = []
+    names = ORDER if sgs != 1 else ORDER[:13]
+    for i, nm in enumerate(names):
+        for j, suf in enumerate(['.weight', '.bias']):
+            a = np.ascontiguousarray(sd[nm + suf], dtype=np.float32)
+            keep.append(a)
+            arr[2 * i + j] = a.ctypes.data
+    blob = np.zeros(n, np.uint8)
+    assert lib.stof_pack_weights(ctypes.byref(desc), arr, blob.ctypes.data, n) == 0
+    return blob.view(np.float32), desc
+
+
+@pytest.mark.parametrize('r,sgs', [(4, 80), (10, 80), (4, 1)])
+def test_pack_layout(lib, r, sgs):
+    sd = synth.synth_state_dict(r, seed=1, semi_global_scale=sgs)
+    f, _ = pack(lib, sd, r, sgs)
+    hdr = f[:64].view(np.uint32)
+    assert hdr[0] == 0x464F5453 and int(hdr[2].view(np.int32)) == r
+    off = 64
+    c1 = f[off:off + 640].reshape(64, 10); off += 640
+    assert np.array_equal(c1[:, :9], sd['conv1.weight'][:, 0, :]) and np.array_equal(c1[:, 9], sd['conv1.bias'])
+    bias = f[off:off + 13 * 64].reshape(13, 64); off += 13 * 64
+    for j in range(1, 12):
+        assert np.array_equal(bias[j], sd[f'conv{j + 1}.bias'])
+    assert np.array_equal(bias[12, :r], sd['conv_last.bias']) and not bias[12, r:].any()
+    chunks = f[off:off + 160 * 2304].reshape(160, 64, 36); off += 160 * 2304
+    c = 0
+    for j in range(1, 13):
+        w = sd['conv_last.weight'] if j == 12 else sd[f'conv{j + 1}.weight']
+        for t in range(w.shape[2]):
+            for hh in range(2):
+                assert np.array_equal(chunks[c, :w.shape[0], :32], w[:, 32 * hh:32 * hh + 32, t])
+                assert not chunks[c, :, 32:].any() and not chunks[c, w.shape[0]:].any()
+                c += 1
+    assert c == 160
+    if sgs != 1:
+        assert np.array_equal(f[off:off + 512], sd['semi_global_block.contract_conv.bias']); off += 512
+        cc = f[off:off + 40 * 4608].reshape(4, 5, 2, 128, 36); off += 40 * 4608
+        wc = sd['semi_global_block.contract_conv.weight']
+        for ocb in range(4):
+            for t in range(5):
+                for hh in range(2):
+                    assert np.array_equal(cc[ocb, t, hh, :, :32], wc[128 * ocb:128 * ocb + 128, 32 * hh:32 * hh + 32, t])
+        ew = f[off:off + 5 * 512 * 64].reshape(5, 512, 64); off += 5 * 512 * 64
+        assert np.array_equal(ew, sd['semi_global_block.expand_conv.weight'].transpose(2, 1, 0))
+        assert np.array_equal(f[off:off + 64], sd['semi_global_block.expand_conv.bias']); off += 64
+    assert off == f.size
+
+
+def test_pack_rejects_bad_args(lib):
+    desc = _lib.NetDesc(0, 80, 0, 0)
+    assert lib.stof_packed_weights_bytes(ctypes.byref(desc)) == 0
+    desc = _lib.NetDesc(4, 40, 0, 0)
+    assert lib.stof_packed_weights_bytes(ctypes.byref(desc)) == 0
+    desc = _lib.NetDesc(4, 80, 0, 0)
+    arr = (ctypes.c_void_p * 30)()
+    blob = np.zeros(16, np.uint8)
+    assert lib.stof_pack_weights(ctypes.byref(desc), arr, blob.ctypes.data, 16) == _lib.STOF_ERR_BAD_ARG
+
+
+def test_module_state_dict_names_match_reference():
+    import torch
+    from stofnet_amd import StofNet
+    m = StofNet(upsample_factor=4)
+    sd = load_weights('different-armadillo')
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == 645764
+    m2 = StofNet(upsample_factor=4, semi_global_scale=1)
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in load_weights('clean-serenity').items()}, strict=True)
+    assert sum(p.numel() for p in m2.parameters()) == 317508
+    with pytest.raises(RuntimeError):       # strict mismatch, as in the reference
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in load_weights('clean-serenity').items()}, strict=True)
+
+
+def test_no_cpu_fallback():
+    import torch
+    from stofnet_amd import StofNet, mask2coords, SampleShuffle1D
+    with pytest.raises(RuntimeError, match='ROCm device only'):
+        StofNet()(torch.zeros(1, 1, 160))
+    with pytest.raises(RuntimeError, match='ROCm device only'):
+        mask2coords(torch.zeros(1, 1, 16), 20)
+    with pytest.raises(RuntimeError, match='ROCm device only'):
+        SampleShuffle1D(4)(torch.zeros(1, 4, 16))

@@ -1,0 +1,317 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the committed golden
+vectors and the CPU oracle.  Run on the MI355X box: pytest -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden, load_weights
+from oracle import pickers_oracle as po
+from oracle import stofnet_oracle as so
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+MANIFEST = json.load(open(os.path.join(GOLDEN, 'manifest.json')))
+MAP_TOL = 1e-5          # relative to max-abs(y), SURVEY.md 8c
+ENV_TOL = 1e-5          # absolute, on max-abs-normalised inputs (north_star)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    import stofnet_amd  # noqa: F401
+    from stofnet_amd import _lib
+    _lib.lib()          # fail loudly if the HIP library is missing
+    return torch.device('cuda:0')
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def make_model(dev, sd, r, sgs=80):
+    from stofnet_amd import StofNet
+    m = StofNet(upsample_factor=r, semi_global_scale=sgs)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m.to(dev).eval()
+
+
+FWD_CASES = [
+    ('f1_armadillo_r4_L2000', 'different-armadillo', 4, 80),
+    ('f1_snow_r4_L1536', 'graceful-snow', 4, 80),
+    ('f1_armadillo_r4_L20000', 'different-armadillo', 4, 80),
+    ('f1_armadillo_r10_L2000', 'different-armadillo', 10, 80),
+    ('f1_snow_r20_L2000', 'graceful-snow', 20, 80),
+    ('f1_serenity_nosgb_r4_L2000', 'clean-serenity', 4, 1),
+]
+
+
+@pytest.mark.parametrize('case,wkey,r,sgs', FWD_CASES)
+def test_forward_matches_reference_golden(dev, case, wkey, r, sgs):
+    g = golden(case)
+    sd = load_weights(wkey)
+    if 'conv_last_weight' in g.files:
+        sd['conv_last.weight'], sd['conv_last.bias'] = g['conv_last_weight'], g['conv_last_bias']
+    m = make_model(dev, sd, r, sgs)
+    y = m(torch.from_numpy(g['x']).to(dev)).cpu().numpy()
+    assert y.shape == g['y'].shape
+    err = rel_err(y, g['y'])
+    assert err < MAP_TOL, f'{case}: rel err {err:.3e}'
+    # integer onset indices (arg-max mode) bit-exact against the reference's maps
+    assert np.array_equal(y[:, 0].argmax(-1), g['y'][:, 0].argmax(-1))
+
+
+def test_forward_seeded_r10(dev):
+    g = golden('f1_seeded_r10_L2000')
+    m = make_model(dev, synth.synth_state_dict(10, seed=3008), 10)
+    y = m(torch.from_numpy(g['x']).to(dev)).cpu().numpy()
+    assert rel_err(y, g['y']) < MAP_TOL
+
+
+@pytest.mark.parametrize('L', [1536, 2000, 2040, 2578, 160, 96])
+def test_sgb_length_quirks(dev, L):
+    g = golden('f3_sgb_lengths')
+    m = make_model(dev, load_weights('different-armadillo'), 4)
+    y = m(torch.from_numpy(g[f'x_L{L}']).to(dev)).cpu().numpy()
+    assert rel_err(y, g[f'y_L{L}']) < MAP_TOL
+
+
+@pytest.mark.parametrize('L', [1999, 2001, 2041])
+def test_sgb_odd_remainder_raises_like_reference(dev, L):
+    m = make_model(dev, load_weights('different-armadillo'), 4)
+    with pytest.raises(RuntimeError, match=r'must match the size of tensor b'):
+        m(torch.zeros(1, 1, L, device=dev))
+
+
+def test_argmax_indices_1024_rows_bit_exact(dev):
+    from stofnet_amd.mask2samples import onset_indices, mask2coords
+    g = golden('f1_armadillo_r4_argmax1024')
+    m = make_model(dev, load_weights('different-armadillo'), 4)
+    x = torch.from_numpy(synth.synth_echo(1024, 2000, seed=int(g['seed']))).to(dev)
+    y = m(x)
+    counts, idx = onset_indices(y, 20, None)
+    ref = g['indices']
+    margins = g['top2'][:, 0] - g['top2'][:, 1]
+    assert np.array_equal(counts.cpu().numpy(), np.ones(1024, np.int32)), 'a row has a tie the reference does not have'
+    got = idx[:, 0].cpu().numpy()
+    bad = np.nonzero(got != ref[:, 1])[0]
+    mae = np.abs(got.astype(np.int64) - ref[:, 1]).mean()
+    assert bad.size == 0, f'{bad.size} flips, MAE {mae}; min margin {margins.min():.3g}; margins at flips {margins[bad]}'
+    assert np.array_equal(mask2coords(y, 20, None, 4).cpu().numpy(), g['coords'])
+
+
+def test_forward_batch_and_workgroup_splits(dev):
+    """Rows are independent: any batch split gives identical bits (the sweep walks several
+    waveforms per work-group; row 0 alone must equal row 0 inside a batch of 300)."""
+    m = make_model(dev, synth.synth_state_dict(4, seed=12), 4)
+    x = torch.from_numpy(synth.synth_randn(300, 400, seed=5)).to(dev)
+    y = m(x)
+    y1 = torch.cat([m(x[:1]), m(x[1:7]), m(x[7:])], 0)
+    assert torch.equal(y, y1)
+    ref = so.stofnet_forward(synth.synth_state_dict(4, seed=12), x[:4].cpu().numpy(), 4, 80).numpy()
+    assert rel_err(y[:4].cpu().numpy(), ref) < MAP_TOL
+
+
+def test_forward_linearity_property_no_sgb_bias_free(dev):
+    """Full-size property check at C2 shape [4096,1,2000]: every row equals the same row
+    computed in a small batch (no cross-row leakage at full occupancy)."""
+    m = make_model(dev, synth.synth_state_dict(10, seed=3008), 10)
+    x = torch.from_numpy(synth.synth_randn(4096, 2000, seed=3008)).to(dev)
+    y = m(x)
+    assert y.shape == (4096, 1, 20000)
+    sel = [0, 1, 255, 256, 2047, 4095]
+    y_small = m(x[sel])
+    assert torch.equal(y[sel], y_small)
+    ref = so.stofnet_forward(synth.synth_state_dict(10, seed=3008), x[sel[:3]].cpu().numpy(), 10, 80).numpy()
+    assert rel_err(y[sel[:3]].cpu().numpy(), ref) < MAP_TOL
+
+
+def test_empty_batch(dev):
+    m = make_model(dev, synth.synth_state_dict(4, seed=1), 4)
+    assert m(torch.zeros(0, 1, 160, device=dev)).shape == (0, 1, 640)
+
+
+# ---------------------------------------------------------------- shuffle
+def test_shuffle_bit_exact(dev):
+    from stofnet_amd import SampleShuffle1D
+    g = golden('f2_shuffle')
+    for r, c in [(4, 1), (10, 1), (20, 1), (4, 16), (3, 2)]:
+        out = SampleShuffle1D(r)(torch.from_numpy(g[f'in_r{r}_c{c}']).to(dev)).cpu().numpy()
+        assert np.array_equal(out, g[f'out_r{r}_c{c}'])
+    with pytest.raises(RuntimeError):
+        SampleShuffle1D(3)(torch.zeros(1, 7, 4, device=dev))
+
+
+@pytest.mark.parametrize('r,C,W,N', [(20, 1, 2000, 64), (10, 1, 2000, 16), (4, 16, 777, 3), (4, 1, 1, 5)])
+def test_shuffle_against_oracle_large(dev, r, C, W, N):
+    from stofnet_amd import SampleShuffle1D
+    x = torch.randn(N, r * C, W, generator=torch.Generator().manual_seed(r * W))
+    out = SampleShuffle1D(r)(x.to(dev)).cpu()
+    assert torch.equal(out, so.sample_shuffle(x, r))
+
+
+def test_shuffle_roundtrip_property_full_size(dev):
+    """C3 size [4096,20,2000] -> [4096,1,40000]: the shuffle is a permutation, so sums of
+    every k-strided slice must equal the channel sums."""
+    from stofnet_amd import SampleShuffle1D
+    x = torch.randint(-8, 8, (4096, 20, 2000), device=dev, dtype=torch.int32).float()
+    out = SampleShuffle1D(20)(x)
+    assert out.shape == (4096, 1, 40000)
+    assert torch.equal(out.view(4096, 2000, 20).permute(0, 2, 1), x)
+
+
+# ---------------------------------------------------------------- picker
+TH = {'none': None, 'zero': 0, '1p5': 1.5, 'neg': -0.75}
+
+
+def test_picker_hand_cases_bit_exact(dev):
+    from stofnet_amd import mask2coords, get_maxima_positions
+    g = golden('f4_picker_hand')
+    names = sorted({f[3:] for f in g.files if f.startswith('in_')})
+    for name in names:
+        s = torch.from_numpy(g['in_' + name]).to(dev)
+        for thn, th in TH.items():
+            idx = get_maxima_positions(s, 20, th).cpu().numpy()
+            assert np.array_equal(idx, g[f'idx_{name}_th{thn}'].reshape(-1, 2)), (name, thn)
+            for em in [None, 3]:
+                exp = g[f'out_{name}_th{thn}_em{em}']
+                out = mask2coords(s, 20, th, 4, em).cpu().numpy()
+                assert out.shape == exp.shape, (name, thn, em)
+                if name == 'tie_nms_neg' and em == 3:
+                    out, exp = out[:2], exp[:2]          # amplitude ties: unspecified in the reference
+                assert np.array_equal(out, exp), (name, thn, em)
+        assert np.array_equal(mask2coords(s, 5, None, 1).cpu().numpy(), g[f'out_{name}_w5'])
+        assert np.array_equal(mask2coords(s, 4, 0.5, 2).cpu().numpy(), g[f'out_{name}_w4_th'])
+
+
+def test_picker_on_network_maps(dev):
+    from stofnet_amd import mask2coords, get_maxima_positions
+    g = golden('f4_picker_on_maps')
+    y = torch.from_numpy(g['y']).to(dev)
+    assert np.array_equal(get_maxima_positions(y, 20, None).cpu().numpy(), g['idx_none'])
+    assert np.array_equal(get_maxima_positions(y, 20, 0.015).cpu().numpy(), g['idx_th'])
+    assert np.array_equal(mask2coords(y, 20, 0.015, 4).cpu().numpy(), g['coords_th'])
+    assert np.array_equal(mask2coords(y, 20, None, 4).cpu().numpy(), g['coords_none'])
+    assert np.array_equal(mask2coords(y, 20, 0.015, 4, 3).cpu().numpy(), g['coords_th_echo3'])
+    assert np.array_equal(mask2coords(y, 20, 0.015, 4, 40).cpu().numpy(), g['coords_th_echo40'])
+
+
+@pytest.mark.parametrize('M,win,th', [(1000, 20, None), (1025, 20, 0.3), (3000, 7, 0.0), (5000, 1, 1.0),
+                                      (40000, 20, None), (17, 20, None), (4097, 128, 0.5)])
+def test_picker_random_vs_oracle(dev, M, win, th):
+    from stofnet_amd import mask2coords
+    rng = np.random.default_rng(M + win)
+    s = rng.standard_normal((5, 1, M)).astype(np.float32)
+    s[1, 0, ::3] = np.round(s[1, 0, ::3])            # exact ties and exact zeros
+    s[2, 0] = np.round(s[2, 0] * 2) / 2
+    out = mask2coords(torch.from_numpy(s).to(dev), win, th, 4).cpu().numpy()
+    assert np.array_equal(out, po.mask2coords(s, win, th, 4))
+
+
+def test_picker_full_size_property(dev):
+    """[4096,1,20000] arg-max mode: every row reports exactly the positions of its maximum."""
+    from stofnet_amd.mask2samples import onset_indices
+    y = torch.randn(4096, 1, 20000, device=dev)
+    counts, idx = onset_indices(y, 20, None)
+    assert torch.equal(counts, torch.ones_like(counts))
+    assert torch.equal(idx[:, 0].long(), y[:, 0].argmax(-1))
+
+
+# ---------------------------------------------------------------- Hilbert
+@pytest.mark.parametrize('n', [7, 16, 1536, 2000, 2001, 8000, 20000])
+def test_hilbert_golden(dev, n):
+    from stofnet_amd import hilbert_transform
+    from stofnet_amd.hilbert import hilbert_envelope
+    g = golden('f5_hilbert')
+    x = torch.from_numpy(g[f'x_n{n}']).to(dev)
+    env = hilbert_envelope(x).cpu().numpy()
+    assert np.abs(env - g[f'env_n{n}']).max() < ENV_TOL
+    v = hilbert_transform(x)
+    assert v.dtype == torch.complex64 and v.shape == x.shape
+    if n <= 2001:
+        assert np.abs(v.real.cpu().numpy() - g[f're_n{n}']).max() < ENV_TOL
+        assert np.abs(v.imag.cpu().numpy() - g[f'im_n{n}']).max() < ENV_TOL
+    # ground truth in float64
+    assert np.abs(env - po.hilbert_envelope(g[f'x_n{n}'])).max() < ENV_TOL
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 31, 97, 1999, 4096, 6000, 10007, 20480])
+def test_hilbert_more_lengths_vs_oracle(dev, n):
+    from stofnet_amd.hilbert import hilbert_envelope
+    x = synth.synth_randn(3, n, seed=n)
+    env = hilbert_envelope(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.abs(env - po.hilbert_envelope(x)).max() < ENV_TOL
+
+
+def test_hilbert_module_concat(dev):
+    from stofnet_amd import HilbertTransform
+    g = golden('f5_hilbert')
+    out = HilbertTransform(concat_oscil=True)(torch.from_numpy(g['concat_in']).to(dev)).cpu().numpy()
+    assert out.shape == g['concat_out'].shape
+    assert np.abs(out - g['concat_out']).max() < ENV_TOL
+
+
+def test_hilbert_real_part_property_full_size(dev):
+    """[4096, 2000]: the real part of the analytic signal is the input (to fp32 rounding)."""
+    from stofnet_amd import hilbert_transform
+    x = torch.from_numpy(synth.synth_randn(4096, 2000, seed=1)).to(dev)
+    v = hilbert_transform(x)
+    assert (v.real - x).abs().max().item() < 1e-5
+
+
+# ---------------------------------------------------------------- GradPeak
+@pytest.mark.parametrize('rf', [10, 20])
+@pytest.mark.parametrize('thn,th', [('none', None), ('1em3', 1e-3), ('1em5', 1e-5)])
+def test_gradpeak_golden(dev, rf, thn, th):
+    from stofnet_amd import GradPeak, toa_detect
+    g = golden('f6_gradpeak')
+    x = torch.from_numpy(g[f'x_rf{rf}']).to(dev)
+    exp_e = g[f'echoes_rf{rf}_th{thn}']
+    got_e = toa_detect(x.squeeze(1), threshold=th, rescale_factor=rf).cpu().numpy()
+    assert got_e.shape == exp_e.shape
+    assert np.array_equal(got_e[..., :2], exp_e[..., :2])          # integer onset / peak indices: exact
+    assert np.abs(got_e[..., 2] - exp_e[..., 2]).max() < ENV_TOL
+    for oo in [True, False]:
+        for emn, em in [('1', 1), ('inf', float('inf')), ('2', 2)]:
+            key = f'out_rf{rf}_th{thn}_onset{int(oo)}_em{emn}'
+            out = GradPeak(threshold=th, rescale_factor=rf, echo_max=em, onset_opt=oo)(x).cpu().numpy()
+            assert np.array_equal(out, g[key]), key
+
+
+def test_gradpeak_gradient_stage(dev):
+    from stofnet_amd import _lib
+    from stofnet_amd.gradpeak import gaussian_kernel_1d
+    g = golden('f6_gradpeak')
+    for rf in [10, 20]:
+        gs = rf // 6 * 5
+        assert np.allclose(gaussian_kernel_1d((gs * 2 - 1) / 6).numpy(), g[f'taps_rf{rf}'], rtol=0, atol=1e-15)
+
+
+def test_gradpeak_degenerate_cases(dev):
+    from stofnet_amd import GradPeak, grad_peak_detect
+    g = golden('f6_gradpeak')
+    out = grad_peak_detect(torch.from_numpy(g['env_q9']).to(dev), grad_step=5, threshold=1e-3, ival_smin=6, ival_smax=300)
+    assert list(out.shape) == MANIFEST['f6_status']['q9_direct'][1] == [3, 0]        # Q9
+    out = grad_peak_detect(torch.from_numpy(g['env_q9'][1:]).to(dev), grad_step=5, threshold=1e-3, ival_smin=6, ival_smax=300)
+    assert np.array_equal(out.cpu().numpy()[..., :2], g['q9_direct_row1_only'][..., :2])
+    assert MANIFEST['f6_status']['noedges'][0] == 'IndexError'
+    with pytest.raises(IndexError):
+        GradPeak(threshold=1e-3, rescale_factor=10, echo_max=1, onset_opt=True)(torch.zeros(2, 1, 300, device=dev))
+    with pytest.raises(ValueError):      # rescale_factor < 6 -> sigma < 0, as in the reference
+        GradPeak(threshold=1e-2, rescale_factor=1)(torch.zeros(2, 1, 300, device=dev))
+
+
+def test_gradpeak_many_rows_vs_oracle(dev):
+    from stofnet_amd import toa_detect
+    x = synth.synth_echo(256, 2000, seed=77, noise=0.01, attack=30, tau=150.0, carrier=0.02)
+    got = toa_detect(torch.from_numpy(x[:, 0]).to(dev), threshold=1e-3, rescale_factor=10).cpu().numpy()
+    exp = po.toa_detect(x[:, 0], 1e-3, 10)
+    assert got.shape == exp.shape
+    same = (got[..., :2] == exp[..., :2]).all(axis=(1, 2))
+    # borderline threshold crossings may differ between fp32 summation orders: report, require >= 99 %
+    assert same.mean() >= 0.99, f'{(~same).sum()} of 256 rows differ'
