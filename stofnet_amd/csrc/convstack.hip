@@ -156,6 +156,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
 
     stage_load(0);
     stage_store(0);
+    // the per-step raw load covers rows [F+4-S, F+4); rows 0..3 of the stream precede the first one
+    if (tid < 4 && tid < L) rawr[tid] = p.x[(size_t)n0 * L + tid];
     __syncthreads();
 
     const int nsteps = (gend - GAP + LAG_LAST + S - 1) / S;
@@ -473,7 +475,9 @@ extern "C" size_t stof_forward_workspace_bytes(const stof_net_desc* desc, int64_
 
 extern "C" int stof_forward(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,
                             int64_t N, int64_t L, void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!desc || !packed_dev || !x || !y || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
+    if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
+    if ((N == 0 || L == 0) && desc->precision == STOF_PREC_FP32) return STOF_OK;   // empty batch: nothing to do
+    if (!packed_dev || !x || !y) return STOF_ERR_BAD_ARG;
     if (desc->precision != STOF_PREC_FP32) return STOF_ERR_UNSUPPORTED;
     const int r = desc->upsample_factor;
     if (r < 1 || r > 64) return STOF_ERR_UNSUPPORTED;

@@ -217,8 +217,9 @@ extern "C" size_t stof_hilbert_workspace_bytes(int64_t N, int64_t n) {
 
 extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, float* re, float* im,
                             void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!x || N < 0 || n < 0 || (!env && !re && !im)) return STOF_ERR_BAD_ARG;
+    if (N < 0 || n < 0) return STOF_ERR_BAD_ARG;
     if (N == 0 || n == 0) return STOF_OK;
+    if (!x || (!env && !re && !im)) return STOF_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < stof_hilbert_workspace_bytes(N, n)) return STOF_ERR_WORKSPACE;
     if (N > 0x7fffffffLL || n > LDS_BYTES / 8) return STOF_ERR_UNSUPPORTED;
     FftPlan plan;

@@ -183,9 +183,10 @@ __global__ __launch_bounds__(256) void indices_to_coords_kernel(const int* __res
 
 extern "C" int stof_sample_shuffle(const float* in, float* out, int64_t N, int64_t C_in, int64_t W, int32_t r,
                                    void* stream) {
-    if (!in || !out || N < 0 || C_in < 0 || W < 0 || r < 1) return STOF_ERR_BAD_ARG;
+    if (N < 0 || C_in < 0 || W < 0 || r < 1) return STOF_ERR_BAD_ARG;
     if (C_in % r != 0) return STOF_ERR_CHANNELS;
     if (N == 0 || C_in == 0 || W == 0) return STOF_OK;
+    if (!in || !out) return STOF_ERR_BAD_ARG;
     if (r > 128) return STOF_ERR_UNSUPPORTED;
     const int64_t C = C_in / r;
     const int64_t tiles_w = (W + SHUF_TW - 1) / SHUF_TW;
@@ -200,9 +201,9 @@ extern "C" int stof_sample_shuffle(const float* in, float* out, int64_t N, int64
 extern "C" int stof_pick_maxima(const float* scores, int64_t N, int64_t M, int32_t window_size,
                                 int32_t has_threshold, float threshold, int32_t* counts, int32_t* idx,
                                 int64_t idx_cap, void* stream) {
-    if (!scores || !counts || (!idx && idx_cap > 0) || N < 0 || M < 0 || idx_cap < 0 || window_size < 0)
-        return STOF_ERR_BAD_ARG;
+    if (N < 0 || M < 0 || idx_cap < 0 || window_size < 0) return STOF_ERR_BAD_ARG;
     if (N == 0) return STOF_OK;
+    if ((!scores && M > 0) || !counts || (!idx && idx_cap > 0)) return STOF_ERR_BAD_ARG;
     const int half = (window_size / 2 * 2 + 1 - 1) / 2;        // utils/mask2samples.py:7-8
     if (half > PK_MAXHALF || M > 0x7fffffffLL || N > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pick_maxima_kernel, dim3((unsigned)N), dim3(256), 0, static_cast<hipStream_t>(stream),
