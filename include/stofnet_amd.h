@@ -89,6 +89,19 @@ int stof_forward(const stof_net_desc* desc, const void* packed_dev,
                  const float* x, float* y, int64_t N, int64_t L,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same as stof_forward, with instrumentation for bench.py: `events` is an array of
+ * STOF_FORWARD_EVENTS hipEvent_t recorded on `stream` before the first kernel and after each
+ * kernel of the first sub-batch (SemiGlobalBlock contract+pool, expand, body sweep), so the
+ * caller can read per-kernel durations with stof_event_elapsed_ms after a sync.
+ * Wraps nothing in the reference (its only timing is time.process_time(), main.py:313-315). */
+#define STOF_FORWARD_EVENTS 4
+int stof_forward_events(const stof_net_desc* desc, const void* packed_dev,
+                        const float* x, float* y, int64_t N, int64_t L,
+                        void* workspace, size_t workspace_bytes, void* stream, void* const* events);
+int stof_events_create(int32_t count, void** events_out);
+int stof_events_destroy(int32_t count, void* const* events);
+int stof_event_elapsed_ms(void* start, void* stop, float* ms_out);
+
 /* SampleShuffle1D.forward (utils/sample_shuffle.py:10-28):
  * in[N, C_in, W] -> out[N, C_in/r, W*r], out[n,c,w*r+k] = in[n,k*C+c,w].     */
 int stof_sample_shuffle(const float* in, float* out, int64_t N, int64_t C_in,

@@ -473,8 +473,9 @@ extern "C" size_t stof_forward_workspace_bytes(const stof_net_desc* desc, int64_
     return (size_t)(nb * P * (NF_SGB + NF)) * sizeof(float) + 256;
 }
 
-extern "C" int stof_forward(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,
-                            int64_t N, int64_t L, void* workspace, size_t workspace_bytes, void* stream_) {
+static int forward_impl(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,
+                        int64_t N, int64_t L, void* workspace, size_t workspace_bytes, void* stream_,
+                        void* const* events) {
     if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     if ((N == 0 || L == 0) && desc->precision == STOF_PREC_FP32) return STOF_OK;   // empty batch: nothing to do
     if (!packed_dev || !x || !y) return STOF_ERR_BAD_ARG;
@@ -533,11 +534,16 @@ extern "C" int stof_forward(const stof_net_desc* desc, const void* packed_dev, c
             sp.x = xb; sp.pooled = pooled; sp.c1 = c1; sp.cbias = cbias; sp.chunks = cchunks;
             sp.N = (int)nb; sp.L = (int)L; sp.P = (int)P;
             sp.tiles_per_wf = (int)((P + SGB_NW - 1) / SGB_NW);
+            if (events && b0 == 0) (void)hipEventRecord(static_cast<hipEvent_t>(events[0]), stream);
             hipLaunchKernelGGL(sgb_contract_pool_kernel<SGB_NW>, dim3((unsigned)(nb * sp.tiles_per_wf)), dim3(256),
                                sgb_lds_bytes(), stream, sp);
+            if (events && b0 == 0) (void)hipEventRecord(static_cast<hipEvent_t>(events[1]), stream);
             const int bpw = (int)((P + EXP_COLS - 1) / EXP_COLS);
             hipLaunchKernelGGL(sgb_expand_kernel, dim3((unsigned)(nb * bpw)), dim3(256), 0, stream,
                                pooled, ew, ebias, sgb, (int)nb, (int)P, bpw);
+            if (events && b0 == 0) (void)hipEventRecord(static_cast<hipEvent_t>(events[2]), stream);
+        } else if (events && b0 == 0) {
+            for (int e = 0; e < 3; ++e) (void)hipEventRecord(static_cast<hipEvent_t>(events[e]), stream);
         }
         BodyParams bp;
         bp.x = xb; bp.sgb = (has_sgb && P > 0) ? sgb : nullptr; bp.y = yb;
@@ -549,7 +555,45 @@ extern "C" int stof_forward(const stof_net_desc* desc, const void* packed_dev, c
         wgs = (nb + bp.wf_per_wg - 1) / bp.wf_per_wg;
         hipLaunchKernelGGL((body_sweep_kernel<BODY_S, BODY_RING, BODY_RAWRING>), dim3((unsigned)wgs), dim3(256),
                            Lds::BYTES, stream, bp);
+        if (events && b0 == 0) (void)hipEventRecord(static_cast<hipEvent_t>(events[3]), stream);
     }
     if (hipGetLastError() != hipSuccess) return STOF_ERR_HIP;
     return STOF_OK;
+}
+
+extern "C" int stof_forward(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,
+                            int64_t N, int64_t L, void* workspace, size_t workspace_bytes, void* stream) {
+    return forward_impl(desc, packed_dev, x, y, N, L, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int stof_forward_events(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,
+                                   int64_t N, int64_t L, void* workspace, size_t workspace_bytes, void* stream,
+                                   void* const* events) {
+    if (!events) return STOF_ERR_BAD_ARG;
+    for (int e = 0; e < STOF_FORWARD_EVENTS; ++e)
+        if (!events[e]) return STOF_ERR_BAD_ARG;
+    return forward_impl(desc, packed_dev, x, y, N, L, workspace, workspace_bytes, stream, events);
+}
+
+extern "C" int stof_events_create(int32_t count, void** events_out) {
+    if (count < 0 || !events_out) return STOF_ERR_BAD_ARG;
+    for (int i = 0; i < count; ++i) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return STOF_ERR_HIP;
+        events_out[i] = ev;
+    }
+    return STOF_OK;
+}
+
+extern "C" int stof_events_destroy(int32_t count, void* const* events) {
+    if (count < 0 || !events) return STOF_ERR_BAD_ARG;
+    for (int i = 0; i < count; ++i)
+        if (events[i]) (void)hipEventDestroy(static_cast<hipEvent_t>(events[i]));
+    return STOF_OK;
+}
+
+extern "C" int stof_event_elapsed_ms(void* start, void* stop, float* ms_out) {
+    if (!start || !stop || !ms_out) return STOF_ERR_BAD_ARG;
+    return hipEventElapsedTime(ms_out, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)) == hipSuccess
+               ? STOF_OK : STOF_ERR_HIP;
 }

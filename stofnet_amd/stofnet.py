@@ -112,7 +112,7 @@ class StofNet(nn.Module):
         return self._packed
 
     # ---- forward -------------------------------------------------------------
-    def forward(self, x):
+    def forward(self, x, _events=None):
         if not self._supported():
             raise NotImplementedError('only the shipped StofNet architecture (64 features, 13 blocks, kernels '
                                       '[9,7,3], 1 input channel, semi_global_scale in {1,80}) has gfx950 kernels')
@@ -130,8 +130,14 @@ class StofNet(nn.Module):
         if self._workspace is None or self._workspace.numel() < ws_bytes or self._workspace.device != x.device:
             self._workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
-            code = lib.stof_forward(ctypes.byref(desc), _lib.ptr(packed), _lib.ptr(xc), _lib.ptr(y), n, L,
-                                    _lib.ptr(self._workspace), self._workspace.numel(), _lib.stream_ptr(x.device))
+            if _events is None:
+                code = lib.stof_forward(ctypes.byref(desc), _lib.ptr(packed), _lib.ptr(xc), _lib.ptr(y), n, L,
+                                        _lib.ptr(self._workspace), self._workspace.numel(),
+                                        _lib.stream_ptr(x.device))
+            else:       # bench.py instrumentation: HIP events around each kernel on the launch stream
+                code = lib.stof_forward_events(ctypes.byref(desc), _lib.ptr(packed), _lib.ptr(xc), _lib.ptr(y), n, L,
+                                               _lib.ptr(self._workspace), self._workspace.numel(),
+                                               _lib.stream_ptr(x.device), _events)
         if code == _lib.STOF_ERR_ODD_SGB_REMAINDER:
             # same failure as models/stofnet.py:115
             got = L // 80 * 80 + 2 * ((L - L // 80 * 80) // 2)
