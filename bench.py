@@ -41,15 +41,39 @@ def total_flops(n, l, r):
     return 2.0 * n * (l * (576 + 163840 + 11 * 28672 + 192 * r) + (l // 80) * 163840)
 
 
-def cpu_baseline(sd, r, sample_rows=256, reps=3):
-    """The oracle (oracle/stofnet_oracle.py, PyTorch CPU fp32) on a bounded sample."""
-    from oracle import stofnet_oracle as so
-    from oracle import synth
+def host_cores():
+    """CPU share of this process: affinity mask capped by the cgroup quota (a GPU box exposes
+    256 hardware threads but grants one job far fewer)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:  # noqa: BLE001
         pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    cores = min(cores, max(1, q // per))
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    env = os.environ.get('STOF_CPU_THREADS')
+    if env:
+        cores = int(env)
+    return min(cores, 64)
+
+
+def cpu_baseline(sd, r, sample_rows=256, reps=3):
+    """The oracle (oracle/stofnet_oracle.py, PyTorch CPU fp32) on a bounded sample."""
+    from oracle import stofnet_oracle as so
+    from oracle import synth
+    cores = host_cores()
     torch.set_num_threads(cores)
     x = synth.synth_randn(sample_rows, L, seed=3008)
     with torch.no_grad():
