@@ -10,36 +10,97 @@
 // All activations between conv1 and the shuffle store live in LDS: body_sweep walks a
 // stream of waveforms left to right in steps of S rows; every layer keeps a frontier that
 // lags 3 rows per conv behind the previous one, the residual stream lives in ring X
-// (updated in place), intermediates in ring Y, and layer weights stream through a
-// double-buffered LDS chunk.  No halo is recomputed and nothing but x, sgb and y touches
-// HBM.  The schedule is emulated in numpy by oracle/sweep_emulator.py.
+// (updated in place), intermediates in ring Y.  No halo is recomputed and nothing but x,
+// sgb and y touches HBM.  The schedule is emulated in numpy by oracle/sweep_emulator.py.
 //
-// Arithmetic: exact fp32 on v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, bit-for-bit
-// fp32), the parity baseline mode (STOF_PREC_FP32).
+// Weights never pass through LDS: they are packed in MFMA-fragment order (stof_common.h) and
+// each wave pulls its next operand fragments from L2 with coalesced 1-KiB loads two chunks
+// ahead of use, so a layer needs one work-group barrier, not one per weight tile.
+//
+// Two arithmetic modes (template PREC):
+//   STOF_PREC_FP32  exact fp32 on v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain): parity baseline
+//   STOF_PREC_F16X3 operands split x = hi + lo in fp16 (|err| ~ 2^-22 |x|), three
+//                   v_mfma_f32_32x32x16_f16 passes hi*hi + hi*lo + lo*hi, fp32 accumulate
 #include <hip/hip_runtime.h>
 #include "stof_common.h"
 
 using namespace stof;
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int LAG_LAST = 34;      // frontier lag of conv_last: 11 convs x 3 + 1
+constexpr int ROWB = ROWF * 4;    // activation row stride in bytes
 
 __device__ __forceinline__ int layer_lag(int j) { return j <= 11 ? 3 * j : LAG_LAST; }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ uint4 ldq(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 
-__device__ __forceinline__ floatx16 mfma4(const float4 a, const float4 b, floatx16 c) {
-    // four K=2 steps: lane (i, h) holds channels 4h..4h+3 of an 8-channel group, step s
-    // contracts channels {s, 4+s}
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+__device__ __forceinline__ float4 as_f4(uint4 v) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ half8 as_h8(uint4 v) {
+    union { uint4 u; half8 h; } c;
+    c.u = v;
+    return c.h;
+}
+
+// D += A * B over 8 channels in exact fp32: lane (i, h) of both operands holds channels
+// 4h..4h+3 of the group, step s contracts channels {s, 4+s}.
+__device__ __forceinline__ floatx16 mma_fp32(uint4 a, uint4 b, floatx16 c) {
+    const float4 af = as_f4(a), bf = as_f4(b);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, c, 0, 0, 0);
     return c;
+}
+// D += (Ah + Al) * (Bh + Bl) without the lo*lo term, over 16 channels.  (Keeping the two cross
+// terms in an accumulator of their own was measured: no accuracy gain worth its 12 % slowdown.)
+__device__ __forceinline__ floatx16 mma_f16x3(uint4 ah, uint4 al, uint4 bh, uint4 bl, floatx16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah), as_h8(bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah), as_h8(bl), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al), as_h8(bh), c, 0, 0, 0);
+    return c;
+}
+
+// Byte offset inside an activation row of operand fragment `frag` (see stof_common.h) for the
+// 32-channel half hh and lane half lh.
+template <int PREC>
+__device__ __forceinline__ int act_frag_off(int frag, int hh, int lh) {
+    if constexpr (PREC == STOF_PREC_FP32) return (32 * hh + 8 * frag + 4 * lh) * 4;
+    else return (32 * hh + 16 * (frag >> 1) + 8 * lh) * 2 + 128 * (frag & 1);
+}
+
+// Store 4 consecutive channels c0..c0+3 of one activation row (row = row base pointer).
+template <int PREC>
+__device__ __forceinline__ void store_act4(char* row, int c0, float4 v) {
+    if constexpr (PREC == STOF_PREC_FP32) {
+        *reinterpret_cast<float4*>(row + 4 * c0) = v;
+    } else {
+        half4 hi, lo;
+        hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+        lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+        lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+        *reinterpret_cast<half4*>(row + 2 * c0) = hi;
+        *reinterpret_cast<half4*>(row + 128 + 2 * c0) = lo;
+    }
+}
+template <int PREC>
+__device__ __forceinline__ float4 load_act4(const char* row, int c0) {
+    if constexpr (PREC == STOF_PREC_FP32) {
+        return *reinterpret_cast<const float4*>(row + 4 * c0);
+    } else {
+        const half4 hi = *reinterpret_cast<const half4*>(row + 2 * c0);
+        const half4 lo = *reinterpret_cast<const half4*>(row + 128 + 2 * c0);
+        return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1],
+                           (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]);
+    }
 }
 
 // ----------------------------------------------------------------------------------
@@ -51,7 +112,7 @@ struct BodyParams {
     float* y;              // [N][L*r]
     const float* c1;       // [64][10]
     const float* bias;     // [13][64]
-    const float* chunks;   // [BODY_NCHUNK][BODY_CHUNK_F]
+    const float* chunks;   // [BODY_NCHUNK][BODY_CHUNK_F] fragment-ordered weights
     int N, L, r, P, rem_half, wf_per_wg;
 };
 
@@ -59,23 +120,21 @@ template <int S, int RING, int RAWRING>
 struct BodyLds {
     static constexpr int X = 0;
     static constexpr int Y = X + RING * ROWF;
-    static constexpr int W = Y + RING * ROWF;
-    static constexpr int RAW = W + 2 * BODY_CHUNK_F;
+    static constexpr int RAW = Y + RING * ROWF;
     static constexpr int BIAS = RAW + RAWRING;
     static constexpr int TOTAL = BIAS + 13 * 64;
     static constexpr size_t BYTES = (size_t)TOTAL * sizeof(float);
 };
 
-template <int S, int RING, int RAWRING>
+template <int PREC, int S, int RING, int RAWRING>
 __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) {
     static_assert((RING & (RING - 1)) == 0 && (RAWRING & (RAWRING - 1)) == 0, "rings are powers of two");
     static_assert(S % 64 == 0 && S + 36 <= RING && S + 42 <= RAWRING, "ring must hold the live span");
     using Lds = BodyLds<S, RING, RAWRING>;
     constexpr int NT = S / 64;                   // N-tiles (32 rows) per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const Xr = smem + Lds::X;
-    float* const Yr = smem + Lds::Y;
-    float* const wbuf = smem + Lds::W;
+    char* const Xr = reinterpret_cast<char*>(smem + Lds::X);
+    char* const Yr = reinterpret_cast<char*>(smem + Lds::Y);
     float* const rawr = smem + Lds::RAW;
     float* const biasl = smem + Lds::BIAS;
 
@@ -92,8 +151,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
     const int gend = (n1 - n0) * Lp;             // local stream rows [0, gend)
 
     // ---- one-time setup: zero rings, biases to LDS, conv1 taps to registers
-    for (int i = tid; i < Lds::W; i += 256) smem[i] = 0.f;
-    for (int i = tid; i < RAWRING; i += 256) rawr[i] = 0.f;
+    for (int i = tid; i < Lds::RAW + RAWRING; i += 256) smem[i] = 0.f;
     for (int i = tid; i < 13 * 64; i += 256) biasl[i] = p.bias[i];
     const int cq = tid & 15, rl = tid >> 4;
     float w1[4][9], b1[4];
@@ -103,9 +161,12 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
         for (int d = 0; d < 9; ++d) w1[i][d] = p.c1[(4 * cq + i) * 10 + d];
         b1[i] = p.c1[(4 * cq + i) * 10 + 9];
     }
+    __syncthreads();
+    // the per-step raw load covers rows [F+4-S, F+4); rows 0..3 of the stream precede the first one
+    if (tid < 4 && tid < L) rawr[tid] = p.x[(size_t)n0 * L + tid];
 
     // relu(conv1(x)) + SemiGlobalBlock contribution for stream rows [rstart, rstart+S) -> ring dst
-    auto x0_pass = [&](float* dst, int rstart) {
+    auto x0_pass = [&](char* dst, int rstart) {
 #pragma unroll 2
         for (int it = 0; it < S / 16; ++it) {
             const int g = rstart + rl + 16 * it;
@@ -132,33 +193,20 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                     v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
                 }
             }
-            float4 o = valid ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            st4(dst + (g & (RING - 1)) * ROWF + 4 * cq, o);
+            const float4 o = valid ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            store_act4<PREC>(dst + (g & (RING - 1)) * ROWB, 4 * cq, o);
         }
     };
 
-    // weight-chunk staging: global -> registers early, registers -> LDS late
-    const float4* const gchunks = reinterpret_cast<const float4*>(p.chunks);
-    constexpr int CHUNK_V4 = BODY_CHUNK_F / 4;   // 576
-    float4 st0, st1, st2;
-    auto stage_load = [&](int c) {
-        const float4* src = gchunks + (size_t)c * CHUNK_V4;
-        st0 = src[tid];
-        st1 = src[tid + 256];
-        if (tid < CHUNK_V4 - 512) st2 = src[tid + 512];
-    };
-    auto stage_store = [&](int buf) {
-        float4* dstv = reinterpret_cast<float4*>(wbuf + buf * BODY_CHUNK_F);
-        dstv[tid] = st0;
-        dstv[tid + 256] = st1;
-        if (tid < CHUNK_V4 - 512) dstv[tid + 512] = st2;
-    };
-
-    stage_load(0);
-    stage_store(0);
-    // the per-step raw load covers rows [F+4-S, F+4); rows 0..3 of the stream precede the first one
-    if (tid < 4 && tid < L) rawr[tid] = p.x[(size_t)n0 * L + tid];
-    __syncthreads();
+    // ---- weight fragments: registers, fetched two chunks ahead of use
+    const uint4* const wbase = reinterpret_cast<const uint4*>(p.chunks) + mi * 64 + lane;
+    auto wload = [&](int c, int f) -> uint4 { return wbase[((size_t)c * FRAGS_PER_CHUNK + f) * 128]; };
+    uint4 wf[2][FRAGS_PER_CHUNK];
+#pragma unroll
+    for (int f = 0; f < FRAGS_PER_CHUNK; ++f) {
+        wf[0][f] = wload(0, f);
+        wf[1][f] = wload(1, f);
+    }
 
     const int nsteps = (gend - GAP + LAG_LAST + S - 1) / S;
     for (int step = 1; step <= nsteps; ++step) {
@@ -185,8 +233,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                 __syncthreads();
             }
             const bool last = (j == 12);
-            const bool reads_x = (j & 1) || (j == 11);
-            const float* const src = reads_x ? Xr : Yr;
+            const bool reads_x = (j & 1);         // conv2,4,..,10 and conv12 read ring X
+            const char* const src = reads_x ? Xr : Yr;
             const int K = last ? 3 : 7, half = K >> 1;
             const int R0 = F - S - layer_lag(j);
             const bool active = !(last && mi == 1 && r <= 32);
@@ -196,85 +244,100 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
 
-            const int nchunk = 2 * K;
-            for (int cc = 0; cc < nchunk; ++cc, ++c) {
+            auto do_chunk = [&](uint4 (&w)[FRAGS_PER_CHUNK], int cc) {
                 const int d = cc >> 1, hh = cc & 1;
-                const int nextc = (c + 1 == BODY_NCHUNK) ? 0 : c + 1;
-                stage_load(nextc);
+                const int c2 = (c + 2 >= BODY_NCHUNK) ? c + 2 - BODY_NCHUNK : c + 2;
                 if (active) {
-                    const float* wb = wbuf + (c & 1) * BODY_CHUNK_F + (32 * mi + ln) * WROWF + 4 * lh;
-                    const float* brow[NT];
+                    const char* brow[NT];
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
                         const int g = R0 + 32 * (NT * ni + k) + ln + d - half;
-                        brow[k] = src + (g & (RING - 1)) * ROWF + 32 * hh + 4 * lh;
+                        brow[k] = src + (g & (RING - 1)) * ROWB;
                     }
+                    if constexpr (PREC == STOF_PREC_FP32) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 a = ld4(wb + 8 * q);
+                        for (int q = 0; q < 4; ++q) {
+                            const int off = act_frag_off<PREC>(q, hh, lh);
 #pragma unroll
-                        for (int k = 0; k < NT; ++k) {
-                            const float4 b = ld4(brow[k] + 8 * q);
-                            acc[k] = mfma4(a, b, acc[k]);
+                            for (int k = 0; k < NT; ++k) acc[k] = mma_fp32(w[q], ldq(brow[k] + off), acc[k]);
+                            w[q] = wload(c2, q);
+                        }
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const int off = act_frag_off<PREC>(2 * ks, hh, lh);
+#pragma unroll
+                            for (int k = 0; k < NT; ++k)
+                                acc[k] = mma_f16x3(w[2 * ks], w[2 * ks + 1], ldq(brow[k] + off),
+                                                   ldq(brow[k] + off + 128), acc[k]);
+                            w[2 * ks] = wload(c2, 2 * ks);
+                            w[2 * ks + 1] = wload(c2, 2 * ks + 1);
                         }
                     }
+                } else {
+#pragma unroll
+                    for (int f = 0; f < FRAGS_PER_CHUNK; ++f) w[f] = wload(c2, f);
                 }
-                if (cc == nchunk - 1) {
-                    // ---- epilogue of sweep layer j (the destination ring is not read by this layer)
-#pragma unroll
-                    for (int k = 0; k < NT; ++k) {
-                        const int g = R0 + 32 * (NT * ni + k) + ln;
-                        const bool inrange = (g >= 0) && (g < gend);
-                        const unsigned nl = inrange ? (unsigned)g / (unsigned)Lp : 0u;
-                        const int t = g - (int)nl * Lp;
-                        const bool valid = inrange && (t < L);
-                        if (!last) {
-                            const bool to_y = (j & 1);          // odd sweep layers (conv2,4,..,10, conv12) write ring Y
-                            float* const dst = to_y ? Yr : Xr;
-                            const bool inplace = !(j & 1) || (j == 11);
-                            const bool act = (j & 1) && (j != 11);
-                            float* const drow = dst + (g & (RING - 1)) * ROWF + 32 * mi + 4 * lh;
-#pragma unroll
-                            for (int gg = 0; gg < 4; ++gg) {
-                                const float4 bb = ld4(biasl + j * 64 + 32 * mi + 8 * gg + 4 * lh);
-                                float4 v = make_float4(acc[k][4 * gg] + bb.x, acc[k][4 * gg + 1] + bb.y,
-                                                       acc[k][4 * gg + 2] + bb.z, acc[k][4 * gg + 3] + bb.w);
-                                if (act) {
-                                    v.x = v.x > 0.f ? v.x : 0.01f * v.x;
-                                    v.y = v.y > 0.f ? v.y : 0.01f * v.y;
-                                    v.z = v.z > 0.f ? v.z : 0.01f * v.z;
-                                    v.w = v.w > 0.f ? v.w : 0.01f * v.w;
-                                }
-                                if (inplace) {
-                                    const float4 o = ld4(drow + 8 * gg);
-                                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                                }
-                                if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                                st4(drow + 8 * gg, v);
-                            }
-                        } else if (active && valid) {
-                            // conv_last + SampleShuffle1D: out[n][t*r + k] = conv_last[n][k][t]
-                            float* const orow = p.y + ((size_t)(n0 + nl) * L + t) * r;
-#pragma unroll
-                            for (int gg = 0; gg < 4; ++gg) {
-                                const int c0 = 32 * mi + 8 * gg + 4 * lh;
-                                const float4 bb = ld4(biasl + 12 * 64 + c0);
-                                const float vv[4] = {acc[k][4 * gg] + bb.x, acc[k][4 * gg + 1] + bb.y,
-                                                     acc[k][4 * gg + 2] + bb.z, acc[k][4 * gg + 3] + bb.w};
-                                if ((r & 3) == 0 && c0 + 3 < r) {
-                                    st4(orow + c0, make_float4(vv[0], vv[1], vv[2], vv[3]));
-                                } else {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e)
-                                        if (c0 + e < r) orow[c0 + e] = vv[e];
-                                }
-                            }
-                        }
-                    }
-                }
-                stage_store((c + 1) & 1);
-                __syncthreads();
+                ++c;
+            };
+            const int nchunk = 2 * K;             // even: the two register sets alternate statically
+            for (int cc = 0; cc < nchunk; cc += 2) {
+                do_chunk(wf[0], cc);
+                do_chunk(wf[1], cc + 1);
             }
+
+            // ---- epilogue of sweep layer j (the destination ring is not read by this layer)
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int g = R0 + 32 * (NT * ni + k) + ln;
+                const bool inrange = (g >= 0) && (g < gend);
+                const unsigned nl = inrange ? (unsigned)g / (unsigned)Lp : 0u;
+                const int t = g - (int)nl * Lp;
+                const bool valid = inrange && (t < L);
+                if (!last) {
+                    char* const dst = (j & 1) ? Yr : Xr;            // odd sweep layers write ring Y
+                    const bool inplace = !(j & 1) || (j == 11);     // residual add: conv3,5,..,11 and conv12
+                    const bool act = (j & 1) && (j != 11);          // leaky ReLU: conv2,4,..,10
+                    char* const drow = dst + (g & (RING - 1)) * ROWB;
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const int c0 = 32 * mi + 8 * gg + 4 * lh;
+                        const float4 bb = ld4(biasl + j * 64 + c0);
+                        float4 v = make_float4(acc[k][4 * gg] + bb.x, acc[k][4 * gg + 1] + bb.y,
+                                               acc[k][4 * gg + 2] + bb.z, acc[k][4 * gg + 3] + bb.w);
+                        if (act) {
+                            v.x = v.x > 0.f ? v.x : 0.01f * v.x;
+                            v.y = v.y > 0.f ? v.y : 0.01f * v.y;
+                            v.z = v.z > 0.f ? v.z : 0.01f * v.z;
+                            v.w = v.w > 0.f ? v.w : 0.01f * v.w;
+                        }
+                        if (inplace) {
+                            const float4 o = load_act4<PREC>(drow, c0);
+                            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                        }
+                        if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        store_act4<PREC>(drow, c0, v);
+                    }
+                } else if (active && valid) {
+                    // conv_last + SampleShuffle1D: out[n][t*r + k] = conv_last[n][k][t]
+                    float* const orow = p.y + ((size_t)(n0 + nl) * L + t) * r;
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const int c0 = 32 * mi + 8 * gg + 4 * lh;
+                        const float4 bb = ld4(biasl + 12 * 64 + c0);
+                        const float vv[4] = {acc[k][4 * gg] + bb.x, acc[k][4 * gg + 1] + bb.y,
+                                             acc[k][4 * gg + 2] + bb.z, acc[k][4 * gg + 3] + bb.w};
+                        if ((r & 3) == 0 && c0 + 3 < r) {
+                            st4(orow + c0, make_float4(vv[0], vv[1], vv[2], vv[3]));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (c0 + e < r) orow[c0 + e] = vv[e];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -293,7 +356,7 @@ struct SgbParams {
     int N, L, P, tiles_per_wf;
 };
 
-template <int NW>
+template <int PREC, int NW>
 __global__ __launch_bounds__(256, 1) void sgb_contract_pool_kernel(const SgbParams p) {
     static_assert(NW % 2 == 0, "80*NW must be a multiple of 32");
     constexpr int ROWS = SGB_SCALE * NW;          // output rows of the tile
@@ -301,9 +364,8 @@ __global__ __launch_bounds__(256, 1) void sgb_contract_pool_kernel(const SgbPara
     constexpr int TR = ROWS + 4;                  // conv1 rows needed (k5: +-2)
     constexpr int RAWN = TR + 8;                  // raw samples needed (k9: +-4)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const act = smem;                      // [TR][ROWF]
-    float* const wbuf = act + TR * ROWF;          // [2][SGB_CHUNK_F]
-    float* const raw = wbuf + 2 * SGB_CHUNK_F;    // [RAWN]
+    char* const act = reinterpret_cast<char*>(smem);          // [TR] rows of ROWB bytes
+    float* const raw = smem + TR * ROWF;                       // [RAWN]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -313,26 +375,19 @@ __global__ __launch_bounds__(256, 1) void sgb_contract_pool_kernel(const SgbPara
     const int L = p.L;
     const int tbase = SGB_SCALE * w0 - 2;         // time of act row 0
 
+    const uint4* const wbase = reinterpret_cast<const uint4*>(p.chunks) + wave * 64 + lane;
+    auto wload = [&](int c, int f) -> uint4 { return wbase[((size_t)c * FRAGS_PER_CHUNK + f) * 256]; };
+    uint4 wf[2][FRAGS_PER_CHUNK];
+#pragma unroll
+    for (int f = 0; f < FRAGS_PER_CHUNK; ++f) {
+        wf[0][f] = wload(0, f);
+        wf[1][f] = wload(1, f);
+    }
+
     for (int i = tid; i < RAWN; i += 256) {
         const int t = tbase - 4 + i;
         raw[i] = (t >= 0 && t < L) ? p.x[(size_t)n * L + t] : 0.f;
     }
-    const float4* const gchunks = reinterpret_cast<const float4*>(p.chunks);
-    constexpr int CHUNK_V4 = SGB_CHUNK_F / 4;     // 1152
-    float4 stg[5];
-    auto stage_load = [&](int c) {
-        const float4* src = gchunks + (size_t)c * CHUNK_V4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stg[i] = src[tid + 256 * i];
-        if (tid < CHUNK_V4 - 1024) stg[4] = src[tid + 1024];
-    };
-    auto stage_store = [&](int buf) {
-        float4* dstv = reinterpret_cast<float4*>(wbuf + buf * SGB_CHUNK_F);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dstv[tid + 256 * i] = stg[i];
-        if (tid < CHUNK_V4 - 1024) dstv[tid + 1024] = stg[4];
-    };
-    stage_load(0);
     __syncthreads();
     {   // relu(conv1) rows of the tile, zero outside [0, L)
         const int cq = tid & 15, rl = tid >> 4;
@@ -354,11 +409,10 @@ __global__ __launch_bounds__(256, 1) void sgb_contract_pool_kernel(const SgbPara
                 v[i] = fmaxf(a, 0.f);
             }
             const bool valid = (t >= 0) && (t < L);
-            st4(act + row * ROWF + 4 * cq,
-                valid ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f));
+            store_act4<PREC>(act + row * ROWB, 4 * cq,
+                             valid ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f));
         }
     }
-    stage_store(0);
     __syncthreads();
 
     int c = 0;
@@ -368,46 +422,61 @@ __global__ __launch_bounds__(256, 1) void sgb_contract_pool_kernel(const SgbPara
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
-        for (int cc = 0; cc < 10; ++cc, ++c) {
+
+        auto do_chunk = [&](uint4 (&w)[FRAGS_PER_CHUNK], int cc) {
             const int d = cc >> 1, hh = cc & 1;
-            if (c + 1 < SGB_NCHUNK) stage_load(c + 1);
-            const float* wb = wbuf + (c & 1) * SGB_CHUNK_F + (32 * wave + ln) * WROWF + 4 * lh;
-            const float* arow = act + (ln + d) * ROWF + 32 * hh + 4 * lh;
+            const int c2 = c + 2;
+            const bool more = c2 < SGB_NCHUNK;
+            const char* arow = act + (ln + d) * ROWB;
+            if constexpr (PREC == STOF_PREC_FP32) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = ld4(wb + 8 * q);
+                for (int q = 0; q < 4; ++q) {
+                    const int off = act_frag_off<PREC>(q, hh, lh);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float4 a = ld4(arow + 32 * m * ROWF + 8 * q);
-                    acc[m] = mfma4(a, b, acc[m]);
+                    for (int m = 0; m < MT; ++m) acc[m] = mma_fp32(ldq(arow + 32 * m * ROWB + off), w[q], acc[m]);
+                    if (more) w[q] = wload(c2, q);
                 }
-            }
-            if (cc == 9) {
-                // pool: accumulator register v of M-tile m is time row 32m + (v&3) + 8(v>>2) + 4*lh,
-                // so an 8-row register group never straddles a window of 80
-                const int oc = 128 * ocb + 32 * wave + ln;
-                const float bias = p.cbias[oc];
-                float wmax[NW];
+            } else {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) wmax[w] = -INFINITY;
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int off = act_frag_off<PREC>(2 * ks, hh, lh);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const int w = (32 * m + 8 * (v >> 2)) / SGB_SCALE;
-                        wmax[w] = fmaxf(wmax[w], acc[m][v]);
+                    for (int m = 0; m < MT; ++m)
+                        acc[m] = mma_f16x3(ldq(arow + 32 * m * ROWB + off), ldq(arow + 32 * m * ROWB + off + 128),
+                                           w[2 * ks], w[2 * ks + 1], acc[m]);
+                    if (more) {
+                        w[2 * ks] = wload(c2, 2 * ks);
+                        w[2 * ks + 1] = wload(c2, 2 * ks + 1);
                     }
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    float mval = fmaxf(wmax[w], __shfl_xor(wmax[w], 32));
-                    mval += bias;
-                    mval = mval > 0.f ? mval : 0.01f * mval;
-                    if (lh == 0 && w0 + w < p.P)
-                        p.pooled[((size_t)n * p.P + w0 + w) * NF_SGB + oc] = mval;
                 }
             }
-            if (c + 1 < SGB_NCHUNK) stage_store((c + 1) & 1);
-            __syncthreads();
+            ++c;
+        };
+        for (int cc = 0; cc < 10; cc += 2) {
+            do_chunk(wf[0], cc);
+            do_chunk(wf[1], cc + 1);
+        }
+        // pool: accumulator register v of M-tile m is time row 32m + (v&3) + 8(v>>2) + 4*lh,
+        // so an 8-row register group never straddles a window of 80
+        const int oc = 128 * ocb + 32 * wave + ln;
+        const float bias = p.cbias[oc];
+        float wmax[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) wmax[w] = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int w = (32 * m + 8 * (v >> 2)) / SGB_SCALE;
+                wmax[w] = fmaxf(wmax[w], acc[m][v]);
+            }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            float mval = fmaxf(wmax[w], __shfl_xor(wmax[w], 32));
+            mval += bias;
+            mval = mval > 0.f ? mval : 0.01f * mval;
+            if (lh == 0 && w0 + w < p.P)
+                p.pooled[((size_t)n * p.P + w0 + w) * NF_SGB + oc] = mval;
         }
     }
 }
@@ -460,38 +529,17 @@ constexpr int BODY_S = 192, BODY_RING = 256, BODY_RAWRING = 256;
 constexpr int SGB_NW = 4;
 constexpr int64_t SUB_BATCH = 4096;      // rows whose SGB maps share one workspace
 
-size_t sgb_lds_bytes() {
-    return (size_t)((SGB_SCALE * SGB_NW + 4) * ROWF + 2 * SGB_CHUNK_F + SGB_SCALE * SGB_NW + 12) * sizeof(float);
+constexpr size_t sgb_lds_bytes() {
+    return (size_t)((SGB_SCALE * SGB_NW + 4) * ROWF + SGB_SCALE * SGB_NW + 12) * sizeof(float);
 }
 
-}  // namespace
-
-extern "C" size_t stof_forward_workspace_bytes(const stof_net_desc* desc, int64_t N, int64_t L) {
-    if (!desc || N <= 0 || L <= 0 || desc->semi_global_scale == 1) return 0;
-    const int64_t nb = N < SUB_BATCH ? N : SUB_BATCH;
-    const int64_t P = L / SGB_SCALE;
-    return (size_t)(nb * P * (NF_SGB + NF)) * sizeof(float) + 256;
-}
-
-static int forward_impl(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,
-                        int64_t N, int64_t L, void* workspace, size_t workspace_bytes, void* stream_,
-                        void* const* events) {
-    if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
-    if ((N == 0 || L == 0) && desc->precision == STOF_PREC_FP32) return STOF_OK;   // empty batch: nothing to do
-    if (!packed_dev || !x || !y) return STOF_ERR_BAD_ARG;
-    if (desc->precision != STOF_PREC_FP32) return STOF_ERR_UNSUPPORTED;
+template <int PREC>
+int launch_forward(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y, int64_t N,
+                   int64_t L, void* workspace, hipStream_t stream, void* const* events) {
     const int r = desc->upsample_factor;
-    if (r < 1 || r > 64) return STOF_ERR_UNSUPPORTED;
     const bool has_sgb = desc->semi_global_scale != 1;
-    if (has_sgb && desc->semi_global_scale != SGB_SCALE) return STOF_ERR_UNSUPPORTED;
-    if (N == 0 || L == 0) return STOF_OK;
     const int64_t P = L / SGB_SCALE;
     const int64_t rem = L - P * SGB_SCALE;
-    if (has_sgb && (rem & 1)) return STOF_ERR_ODD_SGB_REMAINDER;
-    if ((L + GAP) * SUB_BATCH > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;   // local stream rows are int32
-    if (has_sgb && (!workspace || workspace_bytes < stof_forward_workspace_bytes(desc, N, L)))
-        return STOF_ERR_WORKSPACE;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
 
     // layout of the packed blob (mirrors pack_weights.cpp)
     const float* base = static_cast<const float*>(packed_dev);
@@ -507,10 +555,10 @@ static int forward_impl(const stof_net_desc* desc, const void* packed_dev, const
     using Lds = BodyLds<BODY_S, BODY_RING, BODY_RAWRING>;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&body_sweep_kernel<BODY_S, BODY_RING, BODY_RAWRING>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds::BYTES) != hipSuccess)
             return STOF_ERR_HIP;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sgb_contract_pool_kernel<SGB_NW>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sgb_contract_pool_kernel<PREC, SGB_NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sgb_lds_bytes()) != hipSuccess)
             return STOF_ERR_HIP;
         attr_done = true;
@@ -527,6 +575,8 @@ static int forward_impl(const stof_net_desc* desc, const void* packed_dev, const
         float* yb = y + b0 * L * r;
         float* pooled = nullptr;
         float* sgb = nullptr;
+        const bool ev = events && b0 == 0;
+        if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[0]), stream);
         if (has_sgb && P > 0) {
             pooled = static_cast<float*>(workspace);
             sgb = pooled + nb * P * NF_SGB;
@@ -534,16 +584,16 @@ static int forward_impl(const stof_net_desc* desc, const void* packed_dev, const
             sp.x = xb; sp.pooled = pooled; sp.c1 = c1; sp.cbias = cbias; sp.chunks = cchunks;
             sp.N = (int)nb; sp.L = (int)L; sp.P = (int)P;
             sp.tiles_per_wf = (int)((P + SGB_NW - 1) / SGB_NW);
-            if (events && b0 == 0) (void)hipEventRecord(static_cast<hipEvent_t>(events[0]), stream);
-            hipLaunchKernelGGL(sgb_contract_pool_kernel<SGB_NW>, dim3((unsigned)(nb * sp.tiles_per_wf)), dim3(256),
-                               sgb_lds_bytes(), stream, sp);
-            if (events && b0 == 0) (void)hipEventRecord(static_cast<hipEvent_t>(events[1]), stream);
+            hipLaunchKernelGGL((sgb_contract_pool_kernel<PREC, SGB_NW>), dim3((unsigned)(nb * sp.tiles_per_wf)),
+                               dim3(256), sgb_lds_bytes(), stream, sp);
+            if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[1]), stream);
             const int bpw = (int)((P + EXP_COLS - 1) / EXP_COLS);
             hipLaunchKernelGGL(sgb_expand_kernel, dim3((unsigned)(nb * bpw)), dim3(256), 0, stream,
                                pooled, ew, ebias, sgb, (int)nb, (int)P, bpw);
-            if (events && b0 == 0) (void)hipEventRecord(static_cast<hipEvent_t>(events[2]), stream);
-        } else if (events && b0 == 0) {
-            for (int e = 0; e < 3; ++e) (void)hipEventRecord(static_cast<hipEvent_t>(events[e]), stream);
+            if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[2]), stream);
+        } else if (ev) {
+            (void)hipEventRecord(static_cast<hipEvent_t>(events[1]), stream);
+            (void)hipEventRecord(static_cast<hipEvent_t>(events[2]), stream);
         }
         BodyParams bp;
         bp.x = xb; bp.sgb = (has_sgb && P > 0) ? sgb : nullptr; bp.y = yb;
@@ -553,12 +603,42 @@ static int forward_impl(const stof_net_desc* desc, const void* packed_dev, const
         int64_t wgs = nb < ncu ? nb : ncu;
         bp.wf_per_wg = (int)((nb + wgs - 1) / wgs);
         wgs = (nb + bp.wf_per_wg - 1) / bp.wf_per_wg;
-        hipLaunchKernelGGL((body_sweep_kernel<BODY_S, BODY_RING, BODY_RAWRING>), dim3((unsigned)wgs), dim3(256),
+        hipLaunchKernelGGL((body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>), dim3((unsigned)wgs), dim3(256),
                            Lds::BYTES, stream, bp);
-        if (events && b0 == 0) (void)hipEventRecord(static_cast<hipEvent_t>(events[3]), stream);
+        if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[3]), stream);
     }
     if (hipGetLastError() != hipSuccess) return STOF_ERR_HIP;
     return STOF_OK;
+}
+
+int forward_impl(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y, int64_t N, int64_t L,
+                 void* workspace, size_t workspace_bytes, void* stream_, void* const* events) {
+    if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
+    if (desc->precision != STOF_PREC_FP32 && desc->precision != STOF_PREC_F16X3) return STOF_ERR_UNSUPPORTED;
+    const int r = desc->upsample_factor;
+    if (r < 1 || r > 64) return STOF_ERR_UNSUPPORTED;
+    const bool has_sgb = desc->semi_global_scale != 1;
+    if (has_sgb && desc->semi_global_scale != SGB_SCALE) return STOF_ERR_UNSUPPORTED;
+    const int64_t P = L / SGB_SCALE;
+    if (has_sgb && ((L - P * SGB_SCALE) & 1)) return STOF_ERR_ODD_SGB_REMAINDER;
+    if (N == 0 || L == 0) return STOF_OK;                 // empty batch: nothing to do
+    if (!packed_dev || !x || !y) return STOF_ERR_BAD_ARG;
+    if ((L + GAP) * SUB_BATCH > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;   // local stream rows are int32
+    if (has_sgb && (!workspace || workspace_bytes < stof_forward_workspace_bytes(desc, N, L)))
+        return STOF_ERR_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (desc->precision == STOF_PREC_FP32)
+        return launch_forward<STOF_PREC_FP32>(desc, packed_dev, x, y, N, L, workspace, stream, events);
+    return launch_forward<STOF_PREC_F16X3>(desc, packed_dev, x, y, N, L, workspace, stream, events);
+}
+
+}  // namespace
+
+extern "C" size_t stof_forward_workspace_bytes(const stof_net_desc* desc, int64_t N, int64_t L) {
+    if (!desc || N <= 0 || L <= 0 || desc->semi_global_scale == 1) return 0;
+    const int64_t nb = N < SUB_BATCH ? N : SUB_BATCH;
+    const int64_t P = L / SGB_SCALE;
+    return (size_t)(nb * P * (NF_SGB + NF)) * sizeof(float) + 256;
 }
 
 extern "C" int stof_forward(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,

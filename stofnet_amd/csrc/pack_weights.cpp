@@ -29,8 +29,35 @@ static int check_desc(const stof_net_desc* d) {
     if (!d) return STOF_ERR_BAD_ARG;
     if (d->upsample_factor < 1 || d->upsample_factor > 64) return STOF_ERR_UNSUPPORTED;
     if (d->semi_global_scale != 1 && d->semi_global_scale != SGB_SCALE) return STOF_ERR_UNSUPPORTED;
-    if (d->precision != STOF_PREC_FP32) return STOF_ERR_UNSUPPORTED;
+    if (d->precision != STOF_PREC_FP32 && d->precision != STOF_PREC_F16X3) return STOF_ERR_UNSUPPORTED;
     return STOF_OK;
+}
+
+// One chunk = FRAGS_PER_CHUNK fragments x `tiles` output tiles of 32 channels, fragment-major:
+// float offset ((frag * tiles + tile) * 64 + lane) * 4.  Rows >= co are zero (conv_last padding).
+static void pack_chunk(float* dst, int tiles, int row0, const float* w, int co, int ci, int K, int tap, int hh,
+                       int precision) {
+    for (int frag = 0; frag < FRAGS_PER_CHUNK; ++frag)
+        for (int tile = 0; tile < tiles; ++tile)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = row0 + 32 * tile + (lane & 31), hl = lane >> 5;
+                float* out = dst + ((size_t)(frag * tiles + tile) * 64 + lane) * 4;
+                if (precision == STOF_PREC_FP32) {
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 32 * hh + 8 * frag + 4 * hl + e;
+                        out[e] = m < co ? w[((size_t)m * ci + c) * K + tap] : 0.f;
+                    }
+                } else {
+                    const int ks = frag >> 1, part = frag & 1;
+                    _Float16* oh = reinterpret_cast<_Float16*>(out);
+                    for (int e = 0; e < 8; ++e) {
+                        const int c = 32 * hh + 16 * ks + 8 * hl + e;
+                        const float v = m < co ? w[((size_t)m * ci + c) * K + tap] : 0.f;
+                        const _Float16 hi = (_Float16)v;
+                        oh[e] = part == 0 ? hi : (_Float16)(v - (float)hi);
+                    }
+                }
+            }
 }
 
 extern "C" size_t stof_packed_weights_bytes(const stof_net_desc* desc) {
@@ -66,7 +93,7 @@ extern "C" int stof_pack_weights(const stof_net_desc* desc, const float* const* 
         for (int c = 0; c < NF; ++c) base[h.off_bias + j * 64 + c] = params[3 + 2 * (j - 1)][c];
     for (int c = 0; c < r; ++c) base[h.off_bias + 12 * 64 + c] = params[25][c];
 
-    // body chunks in streaming order: layer, tap, half -> [64 out][32 in (+4 pad)]
+    // body chunks in streaming order: (layer, tap, 32-channel half) -> fragments for 2 output tiles
     float* ck = base + h.off_body;
     for (int j = 1; j <= 12; ++j) {
         const bool last = (j == 12);
@@ -75,9 +102,7 @@ extern "C" int stof_pack_weights(const stof_net_desc* desc, const float* const* 
         const int co = last ? r : NF;
         for (int t = 0; t < K; ++t)
             for (int hh = 0; hh < 2; ++hh) {
-                for (int m = 0; m < co; ++m)
-                    for (int cl = 0; cl < 32; ++cl)
-                        ck[m * WROWF + cl] = w[(m * NF + 32 * hh + cl) * K + t];
+                pack_chunk(ck, 2, 0, w, co, NF, K, t, hh, desc->precision);
                 ck += BODY_CHUNK_F;
             }
     }
@@ -88,9 +113,7 @@ extern "C" int stof_pack_weights(const stof_net_desc* desc, const float* const* 
         for (int ocb = 0; ocb < 4; ++ocb)
             for (int t = 0; t < 5; ++t)
                 for (int hh = 0; hh < 2; ++hh) {
-                    for (int o = 0; o < 128; ++o)
-                        for (int cl = 0; cl < 32; ++cl)
-                            cc[o * WROWF + cl] = wc[((128 * ocb + o) * NF + 32 * hh + cl) * 5 + t];
+                    pack_chunk(cc, 4, 128 * ocb, wc, NF_SGB, NF, 5, t, hh, desc->precision);
                     cc += SGB_CHUNK_F;
                 }
         const float* we = params[28];                                   // (64, 512, 5)

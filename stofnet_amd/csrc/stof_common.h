@@ -11,14 +11,24 @@ constexpr int NF_SGB = 512;       // feat_scale * out_channels = 8 * 64 (models/
 constexpr int SGB_SCALE = 80;     // semi_global_scale of every shipped checkpoint
 constexpr int GAP = 4;            // zero rows between waveforms in the body sweep (= conv1 padding)
 
-// LDS geometry (floats).  Activation rows hold 64 channels (256 B) padded to 272 B so
-// that the 16 lanes of a ds_read_b128 group (consecutive time rows, same channel
-// offset) fall on 16 distinct 4-bank groups; weight-chunk rows hold 32 input channels
-// (128 B) padded to 144 B for the same reason.
+// LDS geometry.  An activation row is 256 B of payload padded to 272 B (68 floats) so that the
+// 16 lanes of a ds_read_b128 group (consecutive time rows, same channel offset) fall on 16
+// distinct 4-bank groups.  Payload per precision mode:
+//   fp32  : 64 channels x fp32
+//   f16x3 : 64 channels x fp16 "hi" | 64 channels x fp16 "lo"   (x = hi + lo to ~2^-22)
 constexpr int ROWF = 68;
-constexpr int WROWF = 36;
-constexpr int BODY_CHUNK_F = 64 * WROWF;       // one (layer, tap, 32-channel half): [64 out][36]
-constexpr int SGB_CHUNK_F = 128 * WROWF;       // one (oc block of 128, tap, half): [128 out][36]
+
+// Weights are stored in MFMA-fragment order so that a wave fetches one operand fragment with a
+// single fully coalesced 1-KiB load (lane l gets bytes [16 l, 16 l + 16)) straight into the
+// registers the MFMA reads -- no LDS staging.  A "chunk" is one (layer, tap, 32-input-channel
+// half); it holds FRAGS_PER_CHUNK fragments for each 32-wide output-channel tile:
+//   fp32  : fragment q (0..3)        : lane (m = l&31, h = l>>5) -> W[m][32*half + 8q + 4h + 0..3]   (4 x fp32)
+//   f16x3 : fragment 2*ks + part     : lane (m, h) -> part(W[m][32*half + 16ks + 8h + 0..7])         (8 x fp16)
+//           part 0 = hi, 1 = lo
+constexpr int FRAGS_PER_CHUNK = 4;
+constexpr int FRAG_F = 256;                                   // floats per fragment (1 KiB)
+constexpr int BODY_CHUNK_F = FRAGS_PER_CHUNK * 2 * FRAG_F;    // 2 output tiles (64 channels)
+constexpr int SGB_CHUNK_F = FRAGS_PER_CHUNK * 4 * FRAG_F;     // 4 output tiles (128-channel block)
 constexpr int BODY_CHUNKS_K7 = 14;             // 7 taps x 2 halves
 constexpr int BODY_CHUNKS_LAST = 6;            // 3 taps x 2 halves
 constexpr int BODY_NCHUNK = 11 * BODY_CHUNKS_K7 + BODY_CHUNKS_LAST;   // 160 per sweep step

@@ -35,8 +35,8 @@ ORDER = (['conv1'] + [f'conv{i}' for i in range(2, 13)] + ['conv_last',
          'semi_global_block.contract_conv', 'semi_global_block.expand_conv'])
 
 
-def pack(lib, sd, r, sgs):
-    desc = _lib.NetDesc(r, sgs, 0, 0)
+def pack(lib, sd, r, sgs, prec=0):
+    desc = _lib.NetDesc(r, sgs, prec, 0)
     n = lib.stof_packed_weights_bytes(ctypes.byref(desc))
     arr = (ctypes.c_void_p * 30)()
     keep = []
@@ -51,12 +51,33 @@ def pack(lib, sd, r, sgs):
     return blob.view(np.float32), desc
 
 
-@pytest.mark.parametrize('r,sgs', [(4, 80), (10, 80), (4, 1)])
-def test_pack_layout(lib, r, sgs):
+def unpack_chunk(chunk, tiles, prec):
+    """Invert the fragment order documented in stofnet_amd/csrc/stof_common.h:
+    chunk [4 frags][tiles][64 lanes][16 bytes] -> dense [32*tiles rows][32 channels] (fp32 value)."""
+    raw = chunk.reshape(4, tiles, 64, 4)
+    out = np.zeros((32 * tiles, 32), np.float64)
+    lane = np.arange(64)
+    m, hl = lane & 31, lane >> 5
+    for tile in range(tiles):
+        if prec == 0:
+            for q in range(4):
+                for e in range(4):
+                    out[32 * tile + m, 8 * q + 4 * hl + e] = raw[q, tile, :, e]
+        else:
+            halves = raw.view(np.float16).reshape(4, tiles, 64, 8).astype(np.float64)
+            for ks in range(2):
+                for e in range(8):
+                    out[32 * tile + m, 16 * ks + 8 * hl + e] = halves[2 * ks, tile, :, e] + halves[2 * ks + 1, tile, :, e]
+    return out
+
+
+@pytest.mark.parametrize('r,sgs,prec', [(4, 80, 0), (10, 80, 0), (4, 1, 0), (10, 80, 1), (20, 1, 1)])
+def test_pack_layout(lib, r, sgs, prec):
     sd = synth.synth_state_dict(r, seed=1, semi_global_scale=sgs)
-    f, _ = pack(lib, sd, r, sgs)
+    f, _ = pack(lib, sd, r, sgs, prec)
+    tol = 0.0 if prec == 0 else 2.0 ** -21           # hi + lo reproduces fp32 to ~2^-22 relative
     hdr = f[:64].view(np.uint32)
-    assert hdr[0] == 0x464F5453 and int(hdr[2].view(np.int32)) == r
+    assert hdr[0] == 0x464F5453 and int(hdr[2].view(np.int32)) == r and int(hdr[4].view(np.int32)) == prec
     off = 64
     c1 = f[off:off + 640].reshape(64, 10); off += 640
     assert np.array_equal(c1[:, :9], sd['conv1.weight'][:, 0, :]) and np.array_equal(c1[:, 9], sd['conv1.bias'])
@@ -64,24 +85,28 @@ def test_pack_layout(lib, r, sgs):
     for j in range(1, 12):
         assert np.array_equal(bias[j], sd[f'conv{j + 1}.bias'])
     assert np.array_equal(bias[12, :r], sd['conv_last.bias']) and not bias[12, r:].any()
-    chunks = f[off:off + 160 * 2304].reshape(160, 64, 36); off += 160 * 2304
+    chunks = f[off:off + 160 * 2048].reshape(160, 2048); off += 160 * 2048
     c = 0
     for j in range(1, 13):
         w = sd['conv_last.weight'] if j == 12 else sd[f'conv{j + 1}.weight']
         for t in range(w.shape[2]):
             for hh in range(2):
-                assert np.array_equal(chunks[c, :w.shape[0], :32], w[:, 32 * hh:32 * hh + 32, t])
-                assert not chunks[c, :, 32:].any() and not chunks[c, w.shape[0]:].any()
+                dense = unpack_chunk(chunks[c], 2, prec)
+                ref = np.zeros((64, 32))
+                ref[:w.shape[0]] = w[:, 32 * hh:32 * hh + 32, t]
+                assert np.abs(dense - ref).max() <= tol * np.abs(ref).max()
                 c += 1
     assert c == 160
     if sgs != 1:
         assert np.array_equal(f[off:off + 512], sd['semi_global_block.contract_conv.bias']); off += 512
-        cc = f[off:off + 40 * 4608].reshape(4, 5, 2, 128, 36); off += 40 * 4608
+        cc = f[off:off + 40 * 4096].reshape(4, 5, 2, 4096); off += 40 * 4096
         wc = sd['semi_global_block.contract_conv.weight']
         for ocb in range(4):
             for t in range(5):
                 for hh in range(2):
-                    assert np.array_equal(cc[ocb, t, hh, :, :32], wc[128 * ocb:128 * ocb + 128, 32 * hh:32 * hh + 32, t])
+                    dense = unpack_chunk(cc[ocb, t, hh], 4, prec)
+                    ref = wc[128 * ocb:128 * ocb + 128, 32 * hh:32 * hh + 32, t]
+                    assert np.abs(dense - ref).max() <= tol * np.abs(ref).max()
         ew = f[off:off + 5 * 512 * 64].reshape(5, 512, 64); off += 5 * 512 * 64
         assert np.array_equal(ew, sd['semi_global_block.expand_conv.weight'].transpose(2, 1, 0))
         assert np.array_equal(f[off:off + 64], sd['semi_global_block.expand_conv.bias']); off += 64

@@ -6,9 +6,9 @@ from oracle import stofnet_oracle as so, synth
 from stofnet_amd import StofNet
 
 dev = torch.device('cuda:0')
-def run(sgs, r, L, N, seed=1):
+def run(sgs, r, L, N, seed=1, precision='fp32'):
     sd = synth.synth_state_dict(r, seed=seed, semi_global_scale=sgs)
-    m = StofNet(upsample_factor=r, semi_global_scale=sgs)
+    m = StofNet(upsample_factor=r, semi_global_scale=sgs, precision=precision)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     m = m.to(dev).eval()
     x = synth.synth_randn(N, L, seed=3)
@@ -16,7 +16,7 @@ def run(sgs, r, L, N, seed=1):
     ref = so.stofnet_forward(sd, x, r, sgs, taps=taps).numpy()
     y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
     err = np.abs(y - ref)
-    print(f'sgs={sgs} r={r} L={L} N={N}: max abs err {err.max():.3e} (ref max {np.abs(ref).max():.3e})')
+    print(f'[{precision}] sgs={sgs} r={r} L={L} N={N}: max abs err {err.max():.3e} (ref max {np.abs(ref).max():.3e})')
     if err.max() > 1e-4 * np.abs(ref).max():
         for n in range(min(N, 3)):
             e = err[n, 0].reshape(L, r).max(1)
@@ -35,8 +35,7 @@ def run(sgs, r, L, N, seed=1):
             bad = np.argwhere(ep > 1e-4)
             print('   pooled bad count', len(bad), 'examples', bad[:8].tolist(), 'windows', sorted(set(bad[:, 1].tolist()))[:30], 'oc', sorted(set(bad[:,2].tolist()))[:20])
 
-run(1, 4, 400, 2)
-run(1, 4, 2000, 3)
-run(80, 4, 400, 2)
-run(80, 4, 2000, 3)
-run(80, 10, 1536, 2)
+for prec in ['fp32', 'f16x3']:
+    run(1, 4, 400, 2, precision=prec)
+    run(80, 4, 2000, 3, precision=prec)
+    run(80, 10, 1536, 2, precision=prec)
