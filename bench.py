@@ -92,7 +92,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--precision', default=os.environ.get('STOF_PRECISION', 'fp32'))
+    ap.add_argument('--precision', default=os.environ.get('STOF_PRECISION', 'f16x3'), choices=['fp32', 'f16x3'])
+    ap.add_argument('--no-fp32-extra', action='store_true', help='skip the secondary exact-fp32 measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -175,6 +176,25 @@ def main():
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t1) * 1e3
 
+    # secondary measurement: the exact-fp32 parity-baseline mode, same workload (outside the timed region)
+    fp32_extra = None
+    if args.precision != 'fp32' and not args.no_fp32_extra:
+        m32 = StofNet(upsample_factor=R, precision='fp32')
+        m32.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        m32 = m32.to(dev).eval()
+        m32(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            y32 = m32(x)
+        torch.cuda.synchronize()
+        dt32 = (time.perf_counter() - t1) / 3
+        c32, i32 = onset_indices(y32, 20, None)
+        fp32_extra = {'waveforms_per_s_per_gpu': round(N_ROWS / dt32, 1), 'ms_per_step': round(dt32 * 1e3, 3),
+                      'max_rel_diff_vs_timed_mode': float((y32 - y).abs().max() / y32.abs().max()),
+                      'onset_index_mismatches_vs_timed_mode': int((i32[:, 0] != idx[:, 0]).sum())}
+        del m32, y32
+
     if rank == 0:
         value = world * N_ROWS * args.steps / dt
         body_s = k_ms[2] * 1e-3
@@ -192,7 +212,7 @@ def main():
             'value': round(value, 1), 'unit': 'waveforms/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'fp32' else 'f16x3(split fp16, fp32 accumulate)',
+            'dtype': 'f32' if args.precision == 'fp32' else 'f32 via split-fp16 x3 MFMA operands (hi+lo, fp32 accumulate)',
             'data': 'synthetic',
             'config': {'workload': f'C2 StofNet.forward [{N_ROWS},1,{L}] -> [{N_ROWS},1,{L * R}] per GPU, '
                                    f'upsample_factor={R}, SemiGlobalBlock on, seeded-random weights (seed 3008)',
@@ -204,7 +224,9 @@ def main():
             'kernels_ms': {'sgb_contract_pool': round(float(k_ms[0]), 4), 'sgb_expand': round(float(k_ms[1]), 4),
                            'body_sweep': round(float(k_ms[2]), 4)},
             'whole_forward_tflops': round(total_flops(N_ROWS, L, R) * world * args.steps / dt / 1e12, 2),
-            'extras': {'picker_argmax_ms': round(pick_ms, 3), 'index_gather_ms': None if gather_ms is None else round(gather_ms, 3)},
+            'extras': {'picker_argmax_ms': round(pick_ms, 3),
+                       'index_gather_ms': None if gather_ms is None else round(gather_ms, 3),
+                       'fp32_exact_mode': fp32_extra},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, R)
