@@ -22,6 +22,7 @@
 //   STOF_PREC_F16X3 operands split x = hi + lo in fp16 (|err| ~ 2^-22 |x|), three
 //                   v_mfma_f32_32x32x16_f16 passes hi*hi + hi*lo + lo*hi, fp32 accumulate
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "stof_common.h"
 
 using namespace stof;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
     float* const biasl = smem + Lds::BIAS;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mi = wave & 1, ni = wave >> 1;
     const int ln = lane & 31, lh = lane >> 5;
 
@@ -237,54 +238,76 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             const char* const src = reads_x ? Xr : Yr;
             const int K = last ? 3 : 7, half = K >> 1;
             const int R0 = F - S - layer_lag(j);
-            const bool active = !(last && mi == 1 && r <= 32);
+            // (for conv_last with r <= 32 the waves of the upper output tile multiply zero-padded
+            //  weights: free in wall time, and it keeps the chunk body branch-free)
             floatx16 acc[NT];
 #pragma unroll
             for (int k = 0; k < NT; ++k)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
 
-            auto do_chunk = [&](uint4 (&w)[FRAGS_PER_CHUNK], int cc) {
+            // activation fragments of chunk cc: NT row tiles x 4 fragments (ds_read_b128 each)
+            auto bload = [&](uint4 (&b)[NT][FRAGS_PER_CHUNK], int cc) {
                 const int d = cc >> 1, hh = cc & 1;
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const int g = R0 + 32 * (NT * ni + k) + ln + d - half;
+                    const char* row = src + (g & (RING - 1)) * ROWB;
+#pragma unroll
+                    for (int f = 0; f < FRAGS_PER_CHUNK; ++f) b[k][f] = ldq(row + act_frag_off<PREC>(f, hh, lh));
+                }
+            };
+            // one chunk: MFMAs on (w, bcur) while the ds_reads of the next chunk (bnext) are in flight,
+            // then refill w with the fragments of chunk c+2
+            auto do_chunk = [&](uint4 (&w)[FRAGS_PER_CHUNK], uint4 (&bcur)[NT][FRAGS_PER_CHUNK],
+                                uint4 (&bnext)[NT][FRAGS_PER_CHUNK], int cc) {
                 const int c2 = (c + 2 >= BODY_NCHUNK) ? c + 2 - BODY_NCHUNK : c + 2;
-                if (active) {
-                    const char* brow[NT];
+                bload(bnext, cc + 1);          // past the layer's last chunk this reads rows nobody uses
+                if constexpr (PREC == STOF_PREC_FP32) {
 #pragma unroll
-                    for (int k = 0; k < NT; ++k) {
-                        const int g = R0 + 32 * (NT * ni + k) + ln + d - half;
-                        brow[k] = src + (g & (RING - 1)) * ROWB;
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) acc[k] = mma_fp32(w[q], bcur[k][q], acc[k]);
+                        w[q] = wload(c2, q);
                     }
-                    if constexpr (PREC == STOF_PREC_FP32) {
+                    // interleave: one ds_read behind each of the first MFMAs
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int off = act_frag_off<PREC>(q, hh, lh);
-#pragma unroll
-                            for (int k = 0; k < NT; ++k) acc[k] = mma_fp32(w[q], ldq(brow[k] + off), acc[k]);
-                            w[q] = wload(c2, q);
-                        }
-                    } else {
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            const int off = act_frag_off<PREC>(2 * ks, hh, lh);
-#pragma unroll
-                            for (int k = 0; k < NT; ++k)
-                                acc[k] = mma_f16x3(w[2 * ks], w[2 * ks + 1], ldq(brow[k] + off),
-                                                   ldq(brow[k] + off + 128), acc[k]);
-                            w[2 * ks] = wload(c2, 2 * ks);
-                            w[2 * ks + 1] = wload(c2, 2 * ks + 1);
-                        }
+                    for (int i = 0; i < NT * FRAGS_PER_CHUNK; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 } else {
 #pragma unroll
-                    for (int f = 0; f < FRAGS_PER_CHUNK; ++f) w[f] = wload(c2, f);
+                    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                        for (int k = 0; k < NT; ++k)
+                            acc[k] = mma_f16x3(w[2 * ks], w[2 * ks + 1], bcur[k][2 * ks], bcur[k][2 * ks + 1], acc[k]);
+                        w[2 * ks] = wload(c2, 2 * ks);
+                        w[2 * ks + 1] = wload(c2, 2 * ks + 1);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NT * FRAGS_PER_CHUNK; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
                 }
                 ++c;
             };
-            const int nchunk = 2 * K;             // even: the two register sets alternate statically
-            for (int cc = 0; cc < nchunk; cc += 2) {
-                do_chunk(wf[0], cc);
-                do_chunk(wf[1], cc + 1);
-            }
+            // The chunk loop is fully unrolled (14 chunks for k7 layers, 6 for conv_last): in straight-line
+            // code the compiler counts s_waitcnt vmcnt(N) for the weight prefetch instead of draining it
+            // at a loop header, and the two register sets alternate statically.
+            uint4 bf0[NT][FRAGS_PER_CHUNK], bf1[NT][FRAGS_PER_CHUNK];
+            bload(bf0, 0);
+            auto run_chunks = [&](auto nchunk_c) {
+                constexpr int NCH = decltype(nchunk_c)::value;
+#pragma unroll
+                for (int cc = 0; cc < NCH; cc += 2) {
+                    do_chunk(wf[0], bf0, bf1, cc);
+                    do_chunk(wf[1], bf1, bf0, cc + 1);
+                }
+            };
+            if (last) run_chunks(std::integral_constant<int, BODY_CHUNKS_LAST>{});
+            else run_chunks(std::integral_constant<int, BODY_CHUNKS_K7>{});
 
             // ---- epilogue of sweep layer j (the destination ring is not read by this layer)
 #pragma unroll
@@ -318,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                         if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
                         store_act4<PREC>(drow, c0, v);
                     }
-                } else if (active && valid) {
+                } else if (valid) {
                     // conv_last + SampleShuffle1D: out[n][t*r + k] = conv_last[n][k][t]
                     float* const orow = p.y + ((size_t)(n0 + nl) * L + t) * r;
 #pragma unroll
