@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libstofnet_amd.so')
+LIB_PATH = os.environ.get('STOF_LIB_PATH') or os.path.join(_HERE, 'libstofnet_amd.so')   # override: ablation builds only
 
 STOF_OK = 0
 STOF_ERR_BAD_ARG = 1

@@ -104,6 +104,20 @@ __device__ __forceinline__ float4 load_act4(const char* row, int c0) {
     }
 }
 
+#ifdef STOF_STAMPS
+// diagnostic build: shader-clock stamp with its own wait (cdna_hip_programming.md section 7)
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP_ADD(slot) do { const unsigned long long t_ = stamp(); tsum[slot] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define STAMP_ADD(slot) do {} while (0)
+#endif
+
 // ----------------------------------------------------------------------------------
 // body sweep
 // ----------------------------------------------------------------------------------
@@ -115,6 +129,7 @@ struct BodyParams {
     const float* bias;     // [13][64]
     const float* chunks;   // [BODY_NCHUNK][BODY_CHUNK_F] fragment-ordered weights
     int N, L, r, P, rem_half, wf_per_wg;
+    unsigned long long* stamps;   // diagnostic builds (-DSTOF_STAMPS) only: [wg][wave][8] cycle sums
 };
 
 template <int S, int RING, int RAWRING>
@@ -166,36 +181,50 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
     // the per-step raw load covers rows [F+4-S, F+4); rows 0..3 of the stream precede the first one
     if (tid < 4 && tid < L) rawr[tid] = p.x[(size_t)n0 * L + tid];
 
-    // relu(conv1(x)) + SemiGlobalBlock contribution for stream rows [rstart, rstart+S) -> ring dst
+    // relu(conv1(x)) + SemiGlobalBlock contribution for stream rows [rstart, rstart+S) -> ring dst.
+    // A thread owns 4 channels x NIT consecutive rows: the NIT+8 raw samples it needs are read from
+    // LDS once, rows are decoded incrementally (one division per pass), and every SemiGlobalBlock
+    // load is issued before the first FMA so L2 latency is paid once per pass.
     auto x0_pass = [&](char* dst, int rstart) {
-#pragma unroll 2
-        for (int it = 0; it < S / 16; ++it) {
-            const int g = rstart + rl + 16 * it;
-            const bool inrange = (g >= 0) && (g < gend);
-            const unsigned nl = inrange ? (unsigned)g / (unsigned)Lp : 0u;
-            const int t = g - (int)nl * Lp;
-            const bool valid = inrange && (t < L);
-            float xs[9];
+        constexpr int NIT = S / 16;
+        const int g0 = rstart + rl * NIT;
+        const int gb = max(g0, 0);
+        const unsigned nlb = (unsigned)gb / (unsigned)Lp;
+        const int tb = gb - (int)nlb * Lp;
+        float4 sg[NIT];
+        bool ok[NIT];
 #pragma unroll
-            for (int d = 0; d < 9; ++d) xs[d] = rawr[(g + d - 4) & (RAWRING - 1)];
+        for (int it = 0; it < NIT; ++it) {
+            const int g = g0 + it;
+            int t = tb + (g - gb);
+            unsigned nl = nlb;
+            if (t >= Lp) { t -= Lp; nl += 1; }             // NIT < Lp: at most one wrap
+            ok[it] = (g >= 0) && (g < gend) && (t < L);
+            sg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.sgb != nullptr && ok[it]) {
+                const int pos = t - p.rem_half;
+                if (pos >= 0 && pos < SGB_SCALE * p.P) {
+                    const int w = pos / SGB_SCALE;
+                    sg[it] = ld4(p.sgb + ((size_t)(n0 + nl) * p.P + w) * NF + 4 * cq);
+                }
+            }
+        }
+        float xs[NIT + 8];
+#pragma unroll
+        for (int i = 0; i < NIT + 8; ++i) xs[i] = rawr[(g0 - 4 + i) & (RAWRING - 1)];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float a = b1[i];
 #pragma unroll
-                for (int d = 0; d < 9; ++d) a = fmaf(w1[i][d], xs[d], a);
+                for (int d = 0; d < 9; ++d) a = fmaf(w1[i][d], xs[it + d], a);
                 v[i] = fmaxf(a, 0.f);
             }
-            if (p.sgb != nullptr && valid) {
-                const int pos = t - p.rem_half;
-                if (pos >= 0 && pos < SGB_SCALE * p.P) {
-                    const int w = pos / SGB_SCALE;
-                    const float4 s = ld4(p.sgb + ((size_t)(n0 + nl) * p.P + w) * NF + 4 * cq);
-                    v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
-                }
-            }
-            const float4 o = valid ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            store_act4<PREC>(dst + (g & (RING - 1)) * ROWB, 4 * cq, o);
+            const float4 o = ok[it] ? make_float4(v[0] + sg[it].x, v[1] + sg[it].y, v[2] + sg[it].z, v[3] + sg[it].w)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            store_act4<PREC>(dst + ((g0 + it) & (RING - 1)) * ROWB, 4 * cq, o);
         }
     };
 
@@ -209,6 +238,11 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
         wf[1][f] = wload(1, f);
     }
 
+#ifdef STOF_STAMPS
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = stamp();
+    const unsigned long long tstart = tprev;
+#endif
     const int nsteps = (gend - GAP + LAG_LAST + S - 1) / S;
     for (int step = 1; step <= nsteps; ++step) {
         const int F = step * S;
@@ -224,14 +258,23 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             rawr[g & (RAWRING - 1)] = v;
         }
         __syncthreads();
+        STAMP_ADD(0);                             // raw load + barrier
+#ifndef STOF_ABLATE_X0
         x0_pass(Xr, F - S);                       // sweep layer 0
+#endif
+        STAMP_ADD(1);                             // x0 passes
         __syncthreads();
+        STAMP_ADD(2);                             // barrier waits
 
         int c = 0;                                // chunk index within the step
         for (int j = 1; j <= 12; ++j) {
             if (j == 11) {                        // long skip: seed the destination with x0
+#ifndef STOF_ABLATE_X0
                 x0_pass(Yr, F - S - 33);
+#endif
+                STAMP_ADD(1);
                 __syncthreads();
+                STAMP_ADD(2);
             }
             const bool last = (j == 12);
             const bool reads_x = (j & 1);         // conv2,4,..,10 and conv12 read ring X
@@ -240,11 +283,16 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             const int R0 = F - S - layer_lag(j);
             // (for conv_last with r <= 32 the waves of the upper output tile multiply zero-padded
             //  weights: free in wall time, and it keeps the chunk body branch-free)
+            // accumulators start at the layer's bias (lane (ln, lh) holds channels 32mi + 8gg + 4lh + e)
             floatx16 acc[NT];
 #pragma unroll
-            for (int k = 0; k < NT; ++k)
+            for (int gg = 0; gg < 4; ++gg) {
+                const float4 bb = ld4(biasl + j * 64 + 32 * mi + 8 * gg + 4 * lh);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+                for (int k = 0; k < NT; ++k) {
+                    acc[k][4 * gg] = bb.x; acc[k][4 * gg + 1] = bb.y; acc[k][4 * gg + 2] = bb.z; acc[k][4 * gg + 3] = bb.w;
+                }
+            }
 
             // activation fragments of chunk cc: NT row tiles x 4 fragments (ds_read_b128 each)
             auto bload = [&](uint4 (&b)[NT][FRAGS_PER_CHUNK], int cc) {
@@ -261,7 +309,11 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             // then refill w with the fragments of chunk c+2
             auto do_chunk = [&](uint4 (&w)[FRAGS_PER_CHUNK], uint4 (&bcur)[NT][FRAGS_PER_CHUNK],
                                 uint4 (&bnext)[NT][FRAGS_PER_CHUNK], int cc) {
+#ifdef STOF_ABLATE_W
+                const int c2 = 0;              // timing experiment: always the same (cache-hot) fragments
+#else
                 const int c2 = (c + 2 >= BODY_NCHUNK) ? c + 2 - BODY_NCHUNK : c + 2;
+#endif
                 bload(bnext, cc + 1);          // past the layer's last chunk this reads rows nobody uses
                 if constexpr (PREC == STOF_PREC_FP32) {
 #pragma unroll
@@ -306,63 +358,124 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                     do_chunk(wf[1], bf1, bf0, cc + 1);
                 }
             };
+            STAMP_ADD(3);                         // layer setup + first activation fragments
             if (last) run_chunks(std::integral_constant<int, BODY_CHUNKS_LAST>{});
             else run_chunks(std::integral_constant<int, BODY_CHUNKS_K7>{});
+            STAMP_ADD(4);                         // chunk loop (MFMA)
 
             // ---- epilogue of sweep layer j (the destination ring is not read by this layer)
+#ifdef STOF_ABLATE_EPI
+            {   // timing experiment: keep the MFMAs alive, skip the epilogue
+                float ssum = 0.f;
 #pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                const int g = R0 + 32 * (NT * ni + k) + ln;
-                const bool inrange = (g >= 0) && (g < gend);
-                const unsigned nl = inrange ? (unsigned)g / (unsigned)Lp : 0u;
-                const int t = g - (int)nl * Lp;
-                const bool valid = inrange && (t < L);
+                for (int k = 0; k < NT; ++k)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ssum += acc[k][e];
+                if (ssum == 1.2345e33f) p.y[0] = ssum;
+            }
+            if (false)
+#endif
+            {
+                bool valid[NT];
+                int slot[NT], tt[NT];
+                unsigned nn[NT];
+                bool allvalid = true;
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const int g = R0 + 32 * (NT * ni + k) + ln;
+                    const bool inrange = (g >= 0) && (g < gend);
+                    nn[k] = inrange ? (unsigned)g / (unsigned)Lp : 0u;
+                    tt[k] = g - (int)nn[k] * Lp;
+                    valid[k] = inrange && (tt[k] < L);
+                    slot[k] = g & (RING - 1);
+                    allvalid = allvalid && valid[k];
+                }
+                const bool wave_all_valid = __all(allvalid);          // wave-uniform fast path: no masking
                 if (!last) {
                     char* const dst = (j & 1) ? Yr : Xr;            // odd sweep layers write ring Y
                     const bool inplace = !(j & 1) || (j == 11);     // residual add: conv3,5,..,11 and conv12
                     const bool act = (j & 1) && (j != 11);          // leaky ReLU: conv2,4,..,10
-                    char* const drow = dst + (g & (RING - 1)) * ROWB;
+                    float4 v[NT][4];
 #pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) {
-                        const int c0 = 32 * mi + 8 * gg + 4 * lh;
-                        const float4 bb = ld4(biasl + j * 64 + c0);
-                        float4 v = make_float4(acc[k][4 * gg] + bb.x, acc[k][4 * gg + 1] + bb.y,
-                                               acc[k][4 * gg + 2] + bb.z, acc[k][4 * gg + 3] + bb.w);
-                        if (act) {
-                            v.x = v.x > 0.f ? v.x : 0.01f * v.x;
-                            v.y = v.y > 0.f ? v.y : 0.01f * v.y;
-                            v.z = v.z > 0.f ? v.z : 0.01f * v.z;
-                            v.w = v.w > 0.f ? v.w : 0.01f * v.w;
-                        }
-                        if (inplace) {
-                            const float4 o = load_act4<PREC>(drow, c0);
-                            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                        }
-                        if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        store_act4<PREC>(drow, c0, v);
+                    for (int k = 0; k < NT; ++k)
+#pragma unroll
+                        for (int gg = 0; gg < 4; ++gg)
+                            v[k][gg] = make_float4(acc[k][4 * gg], acc[k][4 * gg + 1], acc[k][4 * gg + 2], acc[k][4 * gg + 3]);
+                    if (inplace) {
+                        // all residual reads first (one latency), then the adds
+                        float4 o[NT][4];
+#pragma unroll
+                        for (int k = 0; k < NT; ++k)
+#pragma unroll
+                            for (int gg = 0; gg < 4; ++gg)
+                                o[k][gg] = load_act4<PREC>(dst + slot[k] * ROWB, 32 * mi + 8 * gg + 4 * lh);
+#pragma unroll
+                        for (int k = 0; k < NT; ++k)
+#pragma unroll
+                            for (int gg = 0; gg < 4; ++gg) {
+                                v[k][gg].x += o[k][gg].x; v[k][gg].y += o[k][gg].y;
+                                v[k][gg].z += o[k][gg].z; v[k][gg].w += o[k][gg].w;
+                            }
+                    } else if (act) {
+#pragma unroll
+                        for (int k = 0; k < NT; ++k)
+#pragma unroll
+                            for (int gg = 0; gg < 4; ++gg) {
+                                // leaky_relu(v, 0.01) = max(v, 0.01 v)
+                                v[k][gg].x = fmaxf(v[k][gg].x, 0.01f * v[k][gg].x);
+                                v[k][gg].y = fmaxf(v[k][gg].y, 0.01f * v[k][gg].y);
+                                v[k][gg].z = fmaxf(v[k][gg].z, 0.01f * v[k][gg].z);
+                                v[k][gg].w = fmaxf(v[k][gg].w, 0.01f * v[k][gg].w);
+                            }
                     }
-                } else if (valid) {
+                    if (!wave_all_valid) {
+#pragma unroll
+                        for (int k = 0; k < NT; ++k)
+                            if (!valid[k]) {
+#pragma unroll
+                                for (int gg = 0; gg < 4; ++gg) v[k][gg] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+#pragma unroll
+                        for (int gg = 0; gg < 4; ++gg)
+                            store_act4<PREC>(dst + slot[k] * ROWB, 32 * mi + 8 * gg + 4 * lh, v[k][gg]);
+                } else {
                     // conv_last + SampleShuffle1D: out[n][t*r + k] = conv_last[n][k][t]
-                    float* const orow = p.y + ((size_t)(n0 + nl) * L + t) * r;
 #pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) {
-                        const int c0 = 32 * mi + 8 * gg + 4 * lh;
-                        const float4 bb = ld4(biasl + 12 * 64 + c0);
-                        const float vv[4] = {acc[k][4 * gg] + bb.x, acc[k][4 * gg + 1] + bb.y,
-                                             acc[k][4 * gg + 2] + bb.z, acc[k][4 * gg + 3] + bb.w};
-                        if ((r & 3) == 0 && c0 + 3 < r) {
-                            st4(orow + c0, make_float4(vv[0], vv[1], vv[2], vv[3]));
-                        } else {
+                    for (int k = 0; k < NT; ++k) {
+                        if (!valid[k]) continue;
+                        float* const orow = p.y + ((size_t)(n0 + nn[k]) * L + tt[k]) * r;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (c0 + e < r) orow[c0 + e] = vv[e];
+                        for (int gg = 0; gg < 4; ++gg) {
+                            const int c0 = 32 * mi + 8 * gg + 4 * lh;
+                            if (c0 >= r) continue;
+                            const float vv[4] = {acc[k][4 * gg], acc[k][4 * gg + 1], acc[k][4 * gg + 2], acc[k][4 * gg + 3]};
+                            if ((r & 3) == 0) {
+                                st4(orow + c0, make_float4(vv[0], vv[1], vv[2], vv[3]));
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (c0 + e < r) orow[c0 + e] = vv[e];
+                            }
                         }
                     }
                 }
             }
+            STAMP_ADD(5);                         // epilogue
             __syncthreads();
+            STAMP_ADD(2);
         }
     }
+#ifdef STOF_STAMPS
+    if (lane == 0 && p.stamps) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = tsum[i];
+        o[6] = stamp() - tstart;
+        o[7] = (unsigned long long)nsteps;
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------
@@ -622,6 +735,10 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         bp.x = xb; bp.sgb = (has_sgb && P > 0) ? sgb : nullptr; bp.y = yb;
         bp.c1 = c1; bp.bias = bias; bp.chunks = body;
         bp.N = (int)nb; bp.L = (int)L; bp.r = r; bp.P = (int)P; bp.rem_half = (int)(rem / 2);
+        bp.stamps = nullptr;
+#ifdef STOF_STAMPS
+        if (workspace) bp.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + (size_t)(nb * P * (NF_SGB + NF)) * sizeof(float) + 256);
+#endif
         // one persistent work-group per CU, each sweeping a contiguous run of waveforms
         int64_t wgs = nb < ncu ? nb : ncu;
         bp.wf_per_wg = (int)((nb + wgs - 1) / wgs);
@@ -661,7 +778,11 @@ extern "C" size_t stof_forward_workspace_bytes(const stof_net_desc* desc, int64_
     if (!desc || N <= 0 || L <= 0 || desc->semi_global_scale == 1) return 0;
     const int64_t nb = N < SUB_BATCH ? N : SUB_BATCH;
     const int64_t P = L / SGB_SCALE;
+#ifdef STOF_STAMPS
+    return (size_t)(nb * P * (NF_SGB + NF)) * sizeof(float) + 256 + 256 * 4 * 8 * 8 + 64;
+#else
     return (size_t)(nb * P * (NF_SGB + NF)) * sizeof(float) + 256;
+#endif
 }
 
 extern "C" int stof_forward(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,
