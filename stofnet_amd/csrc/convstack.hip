@@ -559,38 +559,57 @@ __global__ __launch_bounds__(256, 1) void sgb_contract_pool_kernel(const SgbPara
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
-        auto do_chunk = [&](uint4 (&w)[FRAGS_PER_CHUNK], int cc) {
+        // Pipeline unit = one k-step of a chunk (f16x3: 16 channels, fragments {hi, lo}; fp32: one
+        // 8-channel fragment): while the unit's MT x (3 | 4) MFMAs run, the activation fragments
+        // (MFMA A operand, time on M) of the next unit are read from LDS into the other register set.
+        constexpr int UPC = (PREC == STOF_PREC_FP32) ? 4 : 2;        // units per chunk
+        constexpr int FPU = FRAGS_PER_CHUNK / UPC;                    // fragments per unit
+        constexpr int NUNIT = 10 * UPC;                               // per 128-channel output block
+        auto aload = [&](uint4 (&a)[MT][FPU], int uu) {
+            const int cc = uu / UPC, sub = uu % UPC;
             const int d = cc >> 1, hh = cc & 1;
-            const int c2 = c + 2;
-            const bool more = c2 < SGB_NCHUNK;
             const char* arow = act + (ln + d) * ROWB;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < FPU; ++i)
+                    a[m][i] = ldq(arow + 32 * m * ROWB + act_frag_off<PREC>(sub * FPU + i, hh, lh));
+        };
+        auto do_unit = [&](uint4 (&acur)[MT][FPU], uint4 (&anext)[MT][FPU], int uu) {
+            const int cc = uu / UPC, sub = uu % UPC;
+            uint4 (&w)[FRAGS_PER_CHUNK] = wf[cc & 1];
+            const int c2 = (c + 2 < SGB_NCHUNK) ? c + 2 : 0;     // past the end: harmless reload of chunk 0
+            aload(anext, uu + 1 < NUNIT ? uu + 1 : 0);          // the next output block starts with the same rows
             if constexpr (PREC == STOF_PREC_FP32) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int off = act_frag_off<PREC>(q, hh, lh);
+                for (int m = 0; m < MT; ++m) acc[m] = mma_fp32(acur[m][0], w[sub], acc[m]);
+                w[sub] = wload(c2, sub);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m] = mma_fp32(ldq(arow + 32 * m * ROWB + off), w[q], acc[m]);
-                    if (more) w[q] = wload(c2, q);
+                for (int i = 0; i < MT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             } else {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int off = act_frag_off<PREC>(2 * ks, hh, lh);
+                for (int m = 0; m < MT; ++m)
+                    acc[m] = mma_f16x3(acur[m][0], acur[m][1], w[2 * sub], w[2 * sub + 1], acc[m]);
+                w[2 * sub] = wload(c2, 2 * sub);
+                w[2 * sub + 1] = wload(c2, 2 * sub + 1);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        acc[m] = mma_f16x3(ldq(arow + 32 * m * ROWB + off), ldq(arow + 32 * m * ROWB + off + 128),
-                                           w[2 * ks], w[2 * ks + 1], acc[m]);
-                    if (more) {
-                        w[2 * ks] = wload(c2, 2 * ks);
-                        w[2 * ks + 1] = wload(c2, 2 * ks + 1);
-                    }
+                for (int i = 0; i < MT * FPU; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
-            ++c;
+            if (sub == UPC - 1) ++c;
+            __builtin_amdgcn_sched_barrier(0);      // one scheduling region per unit (keeps the igroup solver fast)
         };
-        for (int cc = 0; cc < 10; cc += 2) {
-            do_chunk(wf[0], cc);
-            do_chunk(wf[1], cc + 1);
+        uint4 af0[MT][FPU], af1[MT][FPU];
+        if (ocb == 0) aload(af0, 0);
+#pragma unroll
+        for (int uu = 0; uu < NUNIT; uu += 2) {
+            do_unit(af0, af1, uu);
+            do_unit(af1, af0, uu + 1);
         }
         // pool: accumulator register v of M-tile m is time row 32m + (v&3) + 8(v>>2) + 4*lh,
         // so an 8-row register group never straddles a window of 80
