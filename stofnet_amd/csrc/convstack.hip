@@ -181,23 +181,36 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
     // the per-step raw load covers rows [F+4-S, F+4); rows 0..3 of the stream precede the first one
     if (tid < 4 && tid < L) rawr[tid] = p.x[(size_t)n0 * L + tid];
 
+    // Row decode without division: (n, t) of stream row (base row + off), given the base row's
+    // (nB, tB); off < S + 64.  One conditional subtraction when Lp >= the offset range, a short
+    // loop otherwise (tiny waveforms).
+    auto decode_row = [&](int nB, int tB, int off, int& n, int& t) {
+        n = nB;
+        t = tB + off;
+        if (Lp >= 2 * S) {
+            if (t >= Lp) { t -= Lp; n += 1; }
+        } else {
+            while (t >= Lp) { t -= Lp; n += 1; }
+        }
+    };
+
     // relu(conv1(x)) + SemiGlobalBlock contribution for stream rows [rstart, rstart+S) -> ring dst.
     // A thread owns 4 channels x NIT consecutive rows: the NIT+8 raw samples it needs are read from
     // LDS once, rows are decoded incrementally (one division per pass), and every SemiGlobalBlock
     // load is issued before the first FMA so L2 latency is paid once per pass.
-    auto x0_pass = [&](char* dst, int rstart) {
+    // (nR, tR) = waveform / time of stream row `rstart`, maintained incrementally by the caller
+    auto x0_pass = [&](char* dst, int rstart, int nR, int tR) {
         constexpr int NIT = S / 16;
         const int g0 = rstart + rl * NIT;
-        const int gb = max(g0, 0);
-        const unsigned nlb = (unsigned)gb / (unsigned)Lp;
-        const int tb = gb - (int)nlb * Lp;
+        int nb, tb;
+        decode_row(nR, tR, rl * NIT, nb, tb);
         float4 sg[NIT];
         bool ok[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int g = g0 + it;
-            int t = tb + (g - gb);
-            unsigned nl = nlb;
+            int t = tb + it;
+            int nl = nb;
             if (t >= Lp) { t -= Lp; nl += 1; }             // NIT < Lp: at most one wrap
             ok[it] = (g >= 0) && (g < gend) && (t < L);
             sg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -244,23 +257,26 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
     const unsigned long long tstart = tprev;
 #endif
     const int nsteps = (gend - GAP + LAG_LAST + S - 1) / S;
+    int nS = 0, tS = 0;                           // waveform / time of stream row F - S (wave-uniform)
     for (int step = 1; step <= nsteps; ++step) {
         const int F = step * S;
+        if (step > 1) {
+            tS += S;
+            while (tS >= Lp) { tS -= Lp; nS += 1; }
+        }
         // raw waveform rows [F+4-S, F+4) into the raw ring (zero in gaps / outside the range)
         if (tid < S) {
             const int g = F + 4 - S + tid;
+            int nl, t;
+            decode_row(nS, tS, 4 + tid, nl, t);
             float v = 0.f;
-            if (g >= 0 && g < gend) {
-                const unsigned nl = (unsigned)g / (unsigned)Lp;
-                const int t = g - (int)nl * Lp;
-                if (t < L) v = p.x[(size_t)(n0 + nl) * L + t];
-            }
+            if (g < gend && t < L) v = p.x[(size_t)(n0 + nl) * L + t];
             rawr[g & (RAWRING - 1)] = v;
         }
         __syncthreads();
         STAMP_ADD(0);                             // raw load + barrier
 #ifndef STOF_ABLATE_X0
-        x0_pass(Xr, F - S);                       // sweep layer 0
+        x0_pass(Xr, F - S, nS, tS);               // sweep layer 0
 #endif
         STAMP_ADD(1);                             // x0 passes
         __syncthreads();
@@ -268,9 +284,12 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
 
         int c = 0;                                // chunk index within the step
         for (int j = 1; j <= 12; ++j) {
+            // waveform / time of the layer's first row R0 = F - S - lag (may precede the stream: n = -1)
+            int nR = nS, tR = tS - layer_lag(j);
+            while (tR < 0) { tR += Lp; nR -= 1; }
             if (j == 11) {                        // long skip: seed the destination with x0
 #ifndef STOF_ABLATE_X0
-                x0_pass(Yr, F - S - 33);
+                x0_pass(Yr, F - S - 33, nR, tR);
 #endif
                 STAMP_ADD(1);
                 __syncthreads();
@@ -377,16 +396,14 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
 #endif
             {
                 bool valid[NT];
-                int slot[NT], tt[NT];
-                unsigned nn[NT];
+                int slot[NT], tt[NT], nn[NT];
                 bool allvalid = true;
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
-                    const int g = R0 + 32 * (NT * ni + k) + ln;
-                    const bool inrange = (g >= 0) && (g < gend);
-                    nn[k] = inrange ? (unsigned)g / (unsigned)Lp : 0u;
-                    tt[k] = g - (int)nn[k] * Lp;
-                    valid[k] = inrange && (tt[k] < L);
+                    const int off = 32 * (NT * ni + k) + ln;
+                    const int g = R0 + off;
+                    decode_row(nR, tR, off, nn[k], tt[k]);
+                    valid[k] = (g >= 0) && (g < gend) && (tt[k] < L);
                     slot[k] = g & (RING - 1);
                     allvalid = allvalid && valid[k];
                 }
@@ -637,7 +654,9 @@ __global__ __launch_bounds__(256, 1) void sgb_contract_pool_kernel(const SgbPara
 }
 
 // expand_conv 512->64 k5 on the pooled grid + lrelu (0.2 % of the FLOPs): plain fp32 FMA.
-// One work-group = 16 pooled columns of one waveform; thread = (oc, group of 4 columns).
+// One work-group = 16 pooled columns of one waveform.  The K = 5 x 512 reduction is split over
+// the 4 waves (128 input channels each) so every weight is fetched once per work-group and
+// feeds 16 FMAs; the partial sums meet in LDS.
 constexpr int EXP_COLS = 16;
 __global__ __launch_bounds__(256) void sgb_expand_kernel(const float* __restrict__ pooled,
                                                          const float* __restrict__ ew,
@@ -645,6 +664,7 @@ __global__ __launch_bounds__(256) void sgb_expand_kernel(const float* __restrict
                                                          float* __restrict__ sgb, int N, int P,
                                                          int blocks_per_wf) {
     __shared__ __attribute__((aligned(16))) float tile[(EXP_COLS + 4) * NF_SGB];
+    __shared__ float part[4][EXP_COLS][NF];
     const int tid = threadIdx.x;
     const int n = blockIdx.x / blocks_per_wf;
     const int wbase = (blockIdx.x - n * blocks_per_wf) * EXP_COLS;
@@ -656,24 +676,31 @@ __global__ __launch_bounds__(256) void sgb_expand_kernel(const float* __restrict
         st4(tile + col * NF_SGB + 4 * c4, v);
     }
     __syncthreads();
-    const int oc = tid & 63, cg = tid >> 6;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int oc = tid & 63, kq = tid >> 6;           // wave kq reduces input channels [128 kq, 128 kq + 128)
+    float acc[EXP_COLS];
+#pragma unroll
+    for (int k = 0; k < EXP_COLS; ++k) acc[k] = 0.f;
     for (int d = 0; d < 5; ++d) {
-        const float* wp = ew + (size_t)d * NF_SGB * NF + oc;
-        const float* tp = tile + (4 * cg + d) * NF_SGB;
+        const float* wp = ew + ((size_t)d * NF_SGB + 128 * kq) * NF + oc;
+        const float* tp = tile + d * NF_SGB + 128 * kq;
 #pragma unroll 4
-        for (int ch = 0; ch < NF_SGB; ++ch) {
+        for (int ch = 0; ch < 128; ++ch) {
             const float w = wp[(size_t)ch * NF];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = fmaf(w, tp[k * NF_SGB + ch], acc[k]);
+            for (int k = 0; k < EXP_COLS; ++k) acc[k] = fmaf(w, tp[k * NF_SGB + ch], acc[k]);
         }
     }
+#pragma unroll
+    for (int k = 0; k < EXP_COLS; ++k) part[kq][k][oc] = acc[k];
+    __syncthreads();
     const float b = ebias[oc];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int w = wbase + 4 * cg + k;
+    for (int kk = 0; kk < EXP_COLS / 4; ++kk) {
+        const int k = 4 * kk + kq;                    // each wave finishes 4 of the 16 columns
+        const int w = wbase + k;
         if (w < P) {
-            float v = acc[k] + b;
+            // fixed summation order over the four K-slices: bitwise reproducible
+            float v = ((part[0][k][oc] + part[1][k][oc]) + (part[2][k][oc] + part[3][k][oc])) + b;
             v = v > 0.f ? v : 0.01f * v;
             sgb[((size_t)n * P + w) * NF + oc] = v;
         }
