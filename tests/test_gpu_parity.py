@@ -160,6 +160,50 @@ def test_forward_full_size_row_independence(dev, precision):
     assert rel_err(y[sel[:3]].cpu().numpy(), ref) < MAP_TOL
 
 
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_config_c3_r20_full_size(dev, precision):
+    """BASELINE config C3: [4096,1,2000] -> [4096,1,40000] at r=20 (shuffle-stress shape)."""
+    sd = load_weights('graceful-snow')
+    g = golden('f1_snow_r20_L2000')
+    sd['conv_last.weight'], sd['conv_last.bias'] = g['conv_last_weight'], g['conv_last_bias']
+    m = make_model(dev, sd, 20, precision=precision)
+    x = torch.from_numpy(synth.synth_echo(4096, 2000, seed=21)).to(dev)
+    x[:2] = torch.from_numpy(g['x']).to(dev)
+    y = m(x)
+    assert y.shape == (4096, 1, 40000)
+    tol = MAP_TOL if precision == 'fp32' else MAP_TOL_F16X3_VS_REF
+    assert rel_err(y[:2].cpu().numpy(), g['y']) < tol                 # golden rows inside the full batch
+    sel = [5, 1000, 4095]
+    assert torch.equal(y[sel], m(x[sel]))                             # row independence at full occupancy
+    ref = so.stofnet_forward(sd, x[sel[:2]].cpu().numpy(), 20, 80).numpy()
+    assert rel_err(y[sel[:2]].cpu().numpy(), ref) < tol
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_config_c4_pala_chunk_threshold_mode(dev, precision):
+    """BASELINE config C4, one per-GPU chunk and a bit: [8192+50 rows,1,1536] (L mod 80 = 16 -> the SGB
+    pad quirk), graceful-snow, mask2coords in threshold mode th=0.015 (bash_scripts/array_pala_params.txt:1).
+    N > 4096 also exercises the internal sub-batching of stof_forward."""
+    from stofnet_amd import mask2coords
+    sd = load_weights('graceful-snow')
+    m = make_model(dev, sd, 4, precision=precision)
+    n = 8192 + 50
+    x = torch.from_numpy(synth.synth_echo(n, 1536, seed=31)).to(dev)
+    y = m(x)
+    assert y.shape == (n, 1, 6144)
+    sel = [0, 4095, 4096, 8191, 8192, n - 1]                          # both sides of the sub-batch seams
+    ref = so.stofnet_forward(sd, x[sel].cpu().numpy(), 4, 80).numpy()
+    tol = MAP_TOL if precision == 'fp32' else MAP_TOL_F16X3_VS_REF
+    assert rel_err(y[sel].cpu().numpy(), ref) < tol
+    coords = mask2coords(y, 20, 0.015, 4)
+    exp = po.mask2coords(y[sel].cpu().numpy(), 20, 0.015, 4)          # picker parity on the GPU's own maps
+    got = coords[sel].cpu().numpy()
+    k = exp.shape[1]
+    assert np.array_equal(got[:, :k], exp) and not got[:, k:].any()
+    # onset indices of the network output vs the oracle's maps (index parity of the whole chain)
+    assert np.array_equal(po.mask2coords(ref, 20, None, 4), mask2coords(y[sel], 20, None, 4).cpu().numpy())
+
+
 def test_empty_batch(dev):
     m = make_model(dev, synth.synth_state_dict(4, seed=1), 4)
     assert m(torch.zeros(0, 1, 160, device=dev)).shape == (0, 1, 640)
