@@ -34,6 +34,11 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int LAG_LAST = 34;      // frontier lag of conv_last: 11 convs x 3 + 1
+#ifndef STOF_SGB_NW
+#define STOF_SGB_NW 2          // measured: 2-window tiles with two work-groups per CU beat 4-window tiles by 8 %
+#endif
+constexpr int SGB_NW = STOF_SGB_NW;                    // pooling windows per work-group tile
+constexpr int SGB_WAVES_PER_SIMD = (SGB_NW <= 2) ? 2 : 1;   // small tiles: two work-groups share a CU
 constexpr int ROWB = ROWF * 4;    // activation row stride in bytes
 
 __device__ __forceinline__ int layer_lag(int j) { return j <= 11 ? 3 * j : LAG_LAST; }
@@ -510,7 +515,7 @@ struct SgbParams {
 };
 
 template <int PREC, int NW>
-__global__ __launch_bounds__(256, 1) void sgb_contract_pool_kernel(const SgbParams p) {
+__global__ __launch_bounds__(256, SGB_WAVES_PER_SIMD) void sgb_contract_pool_kernel(const SgbParams p) {
     static_assert(NW % 2 == 0, "80*NW must be a multiple of 32");
     constexpr int ROWS = SGB_SCALE * NW;          // output rows of the tile
     constexpr int MT = ROWS / 32;
@@ -708,7 +713,6 @@ __global__ __launch_bounds__(256) void sgb_expand_kernel(const float* __restrict
 }
 
 constexpr int BODY_S = 192, BODY_RING = 256, BODY_RAWRING = 256;
-constexpr int SGB_NW = 4;
 constexpr int64_t SUB_BATCH = 4096;      // rows whose SGB maps share one workspace
 
 constexpr size_t sgb_lds_bytes() {

@@ -39,12 +39,28 @@ __host__ void make_plan(int n, FftPlan* p) {
     if (m > 1) { p->radix[p->nstages++] = m; p->needs_second = 1; }
 }
 
-__global__ void twiddle_kernel(float2* __restrict__ tw, int n) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
+// Per-call tables in the workspace: tw[k] = exp(-2 pi i k/n) (double-precision sincospi, rounded
+// once) and hf[p] = H[k(p)]/n, the Hilbert filter (utils/hilbert.py:13-17) at the true frequency
+// k(p) of digit-reversed position p, with the 1/n of the inverse transform folded in.
+__global__ void tables_kernel(float2* __restrict__ tw, float* __restrict__ hf, const FftPlan plan) {
+    const int n = plan.n;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
     double s, c;
-    sincospi(-2.0 * (double)k / (double)n, &s, &c);
-    tw[k] = make_float2((float)c, (float)s);
+    sincospi(-2.0 * (double)p / (double)n, &s, &c);
+    tw[p] = make_float2((float)c, (float)s);
+    int rem = p, mm = n, k = 0, mult = 1;
+    for (int st = 0; st < plan.nstages; ++st) {
+        const int R = plan.radix[st];
+        mm /= R;
+        const int q = rem / mm;
+        rem -= q * mm;
+        k += q * mult;
+        mult *= R;
+    }
+    const int nyq = n / 2;
+    const float h = (k == 0 || k == nyq) ? 1.f : (k < nyq ? 2.f : 0.f);
+    hf[p] = h / (float)n;
 }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -72,23 +88,33 @@ __device__ __forceinline__ void small_dft(float2 (&x)[R], const float2* __restri
         x[1] = cadd(d02, rot);
         x[2] = csub(s02, s13);
         x[3] = csub(d02, rot);
+    } else if constexpr (R == 3) {
+        // w = exp(-+2 pi i/3) = -1/2 -+ i sqrt(3)/2
+        const float2 s12 = cadd(x[1], x[2]), d12 = csub(x[1], x[2]);
+        const float2 t = make_float2(fmaf(-0.5f, s12.x, x[0].x), fmaf(-0.5f, s12.y, x[0].y));
+        const float sn = INV ? 0.8660254037844386f : -0.8660254037844386f;
+        const float2 rot = make_float2(-sn * d12.y, sn * d12.x);          // i * sn * d12
+        x[0] = cadd(x[0], s12);
+        x[1] = cadd(t, rot);
+        x[2] = csub(t, rot);
     } else {
-        float2 w[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) w[k] = tw[(size_t)k * (n / R)];
-        float2 y[R];
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            float2 acc = x[0];
-#pragma unroll
-            for (int k = 1; k < R; ++k) {
-                const float2 ww = w[(q * k) % R];
-                acc = cadd(acc, INV ? cmulc(x[k], ww) : cmul(x[k], ww));
-            }
-            y[q] = acc;
-        }
-#pragma unroll
-        for (int q = 0; q < R; ++q) x[q] = y[q];
+        static_assert(R == 5, "small_dft handles radix 2, 3, 4, 5");
+        // Winograd-style radix 5: c1 = cos(2pi/5), c2 = cos(4pi/5), s1 = sin(2pi/5), s2 = sin(4pi/5)
+        constexpr float c1 = 0.30901699437494745f, c2 = -0.8090169943749475f;
+        const float s1 = INV ? 0.9510565162951535f : -0.9510565162951535f;
+        const float s2 = INV ? 0.5877852522924731f : -0.5877852522924731f;
+        const float2 a14 = cadd(x[1], x[4]), b14 = csub(x[1], x[4]);
+        const float2 a23 = cadd(x[2], x[3]), b23 = csub(x[2], x[3]);
+        const float2 t1 = make_float2(x[0].x + c1 * a14.x + c2 * a23.x, x[0].y + c1 * a14.y + c2 * a23.y);
+        const float2 t2 = make_float2(x[0].x + c2 * a14.x + c1 * a23.x, x[0].y + c2 * a14.y + c1 * a23.y);
+        // i * (s1 b14 + s2 b23) and i * (s2 b14 - s1 b23)
+        const float2 u1 = make_float2(-(s1 * b14.y + s2 * b23.y), s1 * b14.x + s2 * b23.x);
+        const float2 u2 = make_float2(-(s2 * b14.y - s1 * b23.y), s2 * b14.x - s1 * b23.x);
+        x[0] = cadd(x[0], cadd(a14, a23));
+        x[1] = cadd(t1, u1);
+        x[4] = csub(t1, u1);
+        x[2] = cadd(t2, u2);
+        x[3] = csub(t2, u2);
     }
 }
 
@@ -97,8 +123,12 @@ template <int R, bool INV>
 __device__ void stage_small(float2* __restrict__ d, const float2* __restrict__ tw, int n, int m) {
     const int sub = m / R;
     const int tstep = n / m;
+    const float inv_sub = 1.0f / (float)sub;
     for (int b = threadIdx.x; b < n / R; b += blockDim.x) {
-        const int blk = b / sub, j = b - blk * sub;
+        // b / sub without integer division: exact for b < 2^22 (float quotient + one correction)
+        int blk = (int)((float)b * inv_sub);
+        int j = b - blk * sub;
+        if (j < 0) { j += sub; blk -= 1; } else if (j >= sub) { j -= sub; blk += 1; }
         float2* base = d + blk * m + j;
         float2 x[R];
 #pragma unroll
@@ -158,53 +188,55 @@ __device__ void run_stage(float2*& cur, float2*& other, const float2* tw, int n,
     __syncthreads();
 }
 
-__global__ __launch_bounds__(512) void hilbert_kernel(const float* __restrict__ x, const float2* __restrict__ tw,
-                                                      const FftPlan plan, float* __restrict__ env,
+// One work-group transforms rows blockIdx.x, blockIdx.x + gridDim.x, ... so the twiddle table is
+// brought into LDS once per work-group (TW_LDS) instead of being fetched from L2 in every stage.
+template <bool TW_LDS>
+__global__ __launch_bounds__(512) void hilbert_kernel(const float* __restrict__ x, const float2* __restrict__ twg,
+                                                      const float* __restrict__ hf, const FftPlan plan,
+                                                      long long nrows, float* __restrict__ env,
                                                       float* __restrict__ re, float* __restrict__ im) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int n = plan.n;
-    float2* cur = lds;
-    float2* other = lds + n;
-    const size_t row = blockIdx.x;
-    const float* xr = x + row * (size_t)n;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) cur[i] = make_float2(xr[i], 0.f);
-    __syncthreads();
+    float2* const buf0 = lds;
+    float2* const buf1 = lds + n;                                  // only used with a prime radix > 5
+    const float2* tw = twg;
+    if (TW_LDS) {
+        float2* twl = lds + (plan.needs_second ? 2 : 1) * (size_t)n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) twl[i] = twg[i];
+        tw = twl;
+    }
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        float2* cur = buf0;
+        float2* other = buf1;
+        const float* xr = x + row * (size_t)n;
+        __syncthreads();                                           // previous row fully written out
+        for (int i = threadIdx.x; i < n; i += blockDim.x) cur[i] = make_float2(xr[i], 0.f);
+        __syncthreads();
 
-    // forward DIF: block length shrinks n -> 1
-    int m = n;
-    for (int s = 0; s < plan.nstages; ++s) {
-        run_stage<false>(cur, other, tw, n, m, plan.radix[s]);
-        m /= plan.radix[s];
-    }
-    // filter at the true frequency of each (digit-reversed) position, fold in the 1/n of ifft
-    const float inv_n = 1.0f / (float)n;
-    const int nyq = n / 2;
-    for (int p = threadIdx.x; p < n; p += blockDim.x) {
-        int rem = p, mm = n, k = 0, mult = 1;
+        // forward DIF: block length shrinks n -> 1
+        int m = n;
         for (int s = 0; s < plan.nstages; ++s) {
-            const int R = plan.radix[s];
-            mm /= R;
-            const int q = rem / mm;
-            rem -= q * mm;
-            k += q * mult;
-            mult *= R;
+            run_stage<false>(cur, other, tw, n, m, plan.radix[s]);
+            m /= plan.radix[s];
         }
-        const float h = (k == 0 || k == nyq) ? 1.f : (k < nyq ? 2.f : 0.f);
-        const float sc = h * inv_n;
-        float2 v = cur[p];
-        cur[p] = make_float2(v.x * sc, v.y * sc);
-    }
-    __syncthreads();
-    // inverse DIT: stages in reverse order, block length grows 1 -> n
-    for (int s = plan.nstages - 1; s >= 0; --s) {
-        m *= plan.radix[s];
-        run_stage<true>(cur, other, tw, n, m, plan.radix[s]);
-    }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float2 v = cur[i];
-        if (env) env[row * (size_t)n + i] = hypotf(v.x, v.y);
-        if (re) re[row * (size_t)n + i] = v.x;
-        if (im) im[row * (size_t)n + i] = v.y;
+        // filter: H[k(p)]/n per digit-reversed position, from the per-call table
+        for (int p = threadIdx.x; p < n; p += blockDim.x) {
+            const float sc = hf[p];
+            const float2 v = cur[p];
+            cur[p] = make_float2(v.x * sc, v.y * sc);
+        }
+        __syncthreads();
+        // inverse DIT: stages in reverse order, block length grows 1 -> n
+        for (int s = plan.nstages - 1; s >= 0; --s) {
+            m *= plan.radix[s];
+            run_stage<true>(cur, other, tw, n, m, plan.radix[s]);
+        }
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const float2 v = cur[i];
+            if (env) env[row * (size_t)n + i] = hypotf(v.x, v.y);
+            if (re) re[row * (size_t)n + i] = v.x;
+            if (im) im[row * (size_t)n + i] = v.y;
+        }
     }
 }
 
@@ -212,7 +244,7 @@ __global__ __launch_bounds__(512) void hilbert_kernel(const float* __restrict__ 
 
 extern "C" size_t stof_hilbert_workspace_bytes(int64_t N, int64_t n) {
     (void)N;
-    return n > 0 ? (size_t)n * sizeof(float2) + 256 : 0;
+    return n > 0 ? (size_t)n * (sizeof(float2) + sizeof(float)) + 256 : 0;
 }
 
 extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, float* re, float* im,
@@ -224,18 +256,34 @@ extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, fl
     if (N > 0x7fffffffLL || n > LDS_BYTES / 8) return STOF_ERR_UNSUPPORTED;
     FftPlan plan;
     make_plan((int)n, &plan);
-    const size_t lds = (size_t)n * sizeof(float2) * (plan.needs_second ? 2 : 1);
-    if (lds > (size_t)LDS_BYTES) return STOF_ERR_UNSUPPORTED;      // prime factor > 5 and n > 10240
+    const size_t data_lds = (size_t)n * sizeof(float2) * (plan.needs_second ? 2 : 1);
+    if (data_lds > (size_t)LDS_BYTES) return STOF_ERR_UNSUPPORTED;      // prime factor > 5 and n > 10240
+    const bool tw_lds = data_lds + (size_t)n * sizeof(float2) <= (size_t)LDS_BYTES;
+    const size_t lds = data_lds + (tw_lds ? (size_t)n * sizeof(float2) : 0);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hilbert_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hilbert_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&hilbert_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return STOF_ERR_HIP;
         attr_done = true;
     }
     float2* tw = static_cast<float2*>(workspace);
-    hipLaunchKernelGGL(twiddle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, (int)n);
-    hipLaunchKernelGGL(hilbert_kernel, dim3((unsigned)N), dim3(512), lds, stream, x, tw, plan, env, re, im);
+    float* hf = reinterpret_cast<float*>(tw + n);
+    hipLaunchKernelGGL(tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, hf, plan);
+    // persistent-ish grid: as many work-groups as can be resident (LDS-limited), each looping over rows
+    int64_t per_cu = (int64_t)LDS_BYTES / (int64_t)(lds ? lds : 1);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;                                          // 512 threads x 4 = 32 waves per CU
+    int64_t grid = 256 * per_cu;
+    if (grid > N) grid = N;
+    if (tw_lds)
+        hipLaunchKernelGGL(hilbert_kernel<true>, dim3((unsigned)grid), dim3(512), lds, stream, x, tw, hf, plan,
+                           (long long)N, env, re, im);
+    else
+        hipLaunchKernelGGL(hilbert_kernel<false>, dim3((unsigned)grid), dim3(512), lds, stream, x, tw, hf, plan,
+                           (long long)N, env, re, im);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
