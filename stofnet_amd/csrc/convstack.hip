@@ -143,7 +143,8 @@ struct BodyLds {
     static constexpr int Y = X + RING * ROWF;
     static constexpr int RAW = Y + RING * ROWF;
     static constexpr int BIAS = RAW + RAWRING;
-    static constexpr int TOTAL = BIAS + 13 * 64;
+    static constexpr int SGL = BIAS + 13 * 64;           // [8 windows][64 ch] SemiGlobalBlock rows
+    static constexpr int TOTAL = SGL + 8 * 64;
     static constexpr size_t BYTES = (size_t)TOTAL * sizeof(float);
 };
 
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
     char* const Yr = reinterpret_cast<char*>(smem + Lds::Y);
     float* const rawr = smem + Lds::RAW;
     float* const biasl = smem + Lds::BIAS;
+    float* const sgl = smem + Lds::SGL;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -183,9 +185,6 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
         b1[i] = p.c1[(4 * cq + i) * 10 + 9];
     }
     __syncthreads();
-    // the per-step raw load covers rows [F+4-S, F+4); rows 0..3 of the stream precede the first one
-    if (tid < 4 && tid < L) rawr[tid] = p.x[(size_t)n0 * L + tid];
-
     // Row decode without division: (n, t) of stream row (base row + off), given the base row's
     // (nB, tB); off < S + 64.  One conditional subtraction when Lp >= the offset range, a short
     // loop otherwise (tiny waveforms).
@@ -209,29 +208,24 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
         const int g0 = rstart + rl * NIT;
         int nb, tb;
         decode_row(nR, tR, rl * NIT, nb, tb);
-        float4 sg[NIT];
-        bool ok[NIT];
+        float xs[NIT + 8];
+#pragma unroll
+        for (int i = 0; i < NIT + 8; ++i) xs[i] = rawr[(g0 - 4 + i) & (RAWRING - 1)];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int g = g0 + it;
             int t = tb + it;
             int nl = nb;
             if (t >= Lp) { t -= Lp; nl += 1; }             // NIT < Lp: at most one wrap
-            ok[it] = (g >= 0) && (g < gend) && (t < L);
-            sg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.sgb != nullptr && ok[it]) {
+            const bool ok = (g >= 0) && (g < gend) && (t < L);
+            float4 sg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.sgb != nullptr && ok) {
                 const int pos = t - p.rem_half;
                 if (pos >= 0 && pos < SGB_SCALE * p.P) {
-                    const int w = pos / SGB_SCALE;
-                    sg[it] = ld4(p.sgb + ((size_t)(n0 + nl) * p.P + w) * NF + 4 * cq);
+                    const int wid = (n0 + nl) * p.P + pos / SGB_SCALE;      // global window id
+                    sg = ld4(sgl + (wid & 7) * NF + 4 * cq);                // staged by the step prologue
                 }
             }
-        }
-        float xs[NIT + 8];
-#pragma unroll
-        for (int i = 0; i < NIT + 8; ++i) xs[i] = rawr[(g0 - 4 + i) & (RAWRING - 1)];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -240,11 +234,43 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                 for (int d = 0; d < 9; ++d) a = fmaf(w1[i][d], xs[it + d], a);
                 v[i] = fmaxf(a, 0.f);
             }
-            const float4 o = ok[it] ? make_float4(v[0] + sg[it].x, v[1] + sg[it].y, v[2] + sg[it].z, v[3] + sg[it].w)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 o = ok ? make_float4(v[0] + sg.x, v[1] + sg.y, v[2] + sg.z, v[3] + sg.w)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
             store_act4<PREC>(dst + ((g0 + it) & (RING - 1)) * ROWB, 4 * cq, o);
         }
     };
+
+    // Per-step global fetches, issued one step ahead: thread tid < S owns raw row Fn+4-S+tid; the
+    // four probe rows Fn-S + {0, 80, 160, S-1} hit every 80-sample window that meets [Fn-S, Fn), and
+    // the 64 threads of probe q fetch that window's 64 channels.  (nB, tB) decode row Fn - S.
+    float raw_next = 0.f, sg_next = 0.f;
+    int sg_slot = -1;
+    auto fetch_step = [&](int Fn, int nB, int tB) {
+        raw_next = 0.f;
+        if (tid < S) {
+            const int g = Fn + 4 - S + tid;
+            int nl, t;
+            decode_row(nB, tB, 4 + tid, nl, t);
+            if (g < gend && t < L) raw_next = p.x[(size_t)(n0 + nl) * L + t];
+        }
+        sg_slot = -1;
+        if (p.sgb != nullptr) {
+            const int q = tid >> 6;
+            const int off = q == 3 ? S - 1 : 80 * q;
+            const int g = Fn - S + off;
+            int nl, t;
+            decode_row(nB, tB, off, nl, t);
+            const int pos = t - p.rem_half;
+            if (g < gend && t < L && pos >= 0 && pos < SGB_SCALE * p.P) {
+                const int wid = (n0 + nl) * p.P + pos / SGB_SCALE;
+                sg_slot = wid & 7;
+                sg_next = p.sgb[(size_t)wid * NF + (tid & 63)];
+            }
+        }
+    };
+    static_assert(S <= 240 && S > 160, "probe offsets {0, 80, 160, S-1} assume 160 < S <= 240");
+    if (tid < 4 && tid < L) rawr[tid] = p.x[(size_t)n0 * L + tid];      // rows 0..3 precede the first fetch
+    fetch_step(S, 0, 0);
 
     // ---- weight fragments: registers, fetched two chunks ahead of use
     const uint4* const wbase = reinterpret_cast<const uint4*>(p.chunks) + mi * 64 + lane;
@@ -269,14 +295,15 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             tS += S;
             while (tS >= Lp) { tS -= Lp; nS += 1; }
         }
-        // raw waveform rows [F+4-S, F+4) into the raw ring (zero in gaps / outside the range)
-        if (tid < S) {
-            const int g = F + 4 - S + tid;
-            int nl, t;
-            decode_row(nS, tS, 4 + tid, nl, t);
-            float v = 0.f;
-            if (g < gend && t < L) v = p.x[(size_t)(n0 + nl) * L + t];
-            rawr[g & (RAWRING - 1)] = v;
+        // The raw samples [F+4-S, F+4) and the SemiGlobalBlock rows of the windows that meet
+        // [F-S, F) were fetched into registers one step ago (or by the prologue): land them in LDS,
+        // then start the fetch for the next step so its latency hides behind this step's MFMAs.
+        if (tid < S) rawr[(F + 4 - S + tid) & (RAWRING - 1)] = raw_next;
+        if (sg_slot >= 0) sgl[sg_slot * NF + (tid & 63)] = sg_next;
+        {
+            int nN = nS, tN = tS + S;                     // decode of row F (first row of the next step)
+            while (tN >= Lp) { tN -= Lp; nN += 1; }
+            fetch_step(F + S, nN, tN);
         }
         __syncthreads();
         STAMP_ADD(0);                             // raw load + barrier
