@@ -149,6 +149,22 @@ int stof_gradpeak_pair(const float* env, const float* grad, int64_t N, int64_t L
                        float* echoes, int64_t cap, int32_t* counts, int32_t* flags,
                        void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Neighbours of the hot path (SURVEY.md section 8f "next rows").
+ * ------------------------------------------------------------------------- */
+
+/* ChirpDataset.iq2rf (datasets/chirp_dataset.py:80-91) + NormalizeVol
+ * (utils/transforms.py:13): iq[N, len, 2] (re, im) fp32 -> rf[N, int(len*rescale_factor)] fp32:
+ * linear resampling on endpoint-inclusive grids, Re{y * exp(2 pi i fc t)}, then (normalize != 0)
+ * division by the per-waveform max |.|.                                         */
+int stof_iq2rf(const float* iq, float* rf, int64_t N, int64_t len, double rescale_factor,
+               double fc, double fs, int32_t normalize, void* stream);
+
+/* toa_rmse (utils/metrics.py:9-41): gt[N, G], es[N, E] fp32 with 0/NaN/inf as padding ->
+ * out[N, 7] = (rmse, precision, recall, jaccard, tp, fp, fn).                  */
+int stof_toa_rmse(const float* gt, const float* es, int64_t N, int64_t G, int64_t E, float tol,
+                  float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

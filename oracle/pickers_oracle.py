@@ -290,3 +290,23 @@ def gaussian_kernel(size, sigma=1.0) -> np.ndarray:
     x = np.linspace(-size // 2 + 1, size // 2, size)
     k = np.exp(-np.power(x / sigma, 2) / 2)
     return k / np.sum(k)
+
+
+# --------------------------------------------------------------------------
+# dataset-side RF preparation (datasets/chirp_dataset.py:80-91, utils/transforms.py:13)
+# --------------------------------------------------------------------------
+def iq2rf(iq_data: np.ndarray, fc: float, fs: float, rescale_factor=1, normalize=True) -> np.ndarray:
+    """The same numpy/scipy calls the reference makes (the arithmetic lives in scipy.interpolate.interp1d):
+    linear resampling of the complex IQ trace on endpoint-inclusive grids, up-mixing, real part, then
+    NormalizeVol.  float64, one row at a time; returns float64 [N, int(len*rescale_factor)]."""
+    from scipy.interpolate import interp1d
+    iq = np.asarray(iq_data)
+    out = []
+    for row in iq:
+        n = row.shape[0]
+        x = np.linspace(0, n / fs, num=n, endpoint=True)
+        t = np.linspace(0, n / fs, num=int(n * rescale_factor), endpoint=True)
+        y = interp1d(x, row, axis=0)(t)
+        rf = (y * np.exp(2j * np.pi * fc * t)).real
+        out.append(rf / np.abs(rf).max() if normalize else rf)
+    return np.stack(out)

@@ -388,3 +388,37 @@ def test_gradpeak_many_rows_vs_oracle(dev):
     same = (got[..., :2] == exp[..., :2]).all(axis=(1, 2))
     # borderline threshold crossings may differ between fp32 summation orders: report, require >= 99 %
     assert same.mean() >= 0.99, f'{(~same).sum()} of 256 rows differ'
+
+
+# ---------------------------------------------------------------- neighbours of the path
+def test_toa_rmse_device(dev):
+    from stofnet_amd.metrics import toa_rmse
+    g = golden('f7_metrics')
+    for tol in [1, 4]:
+        got = toa_rmse(torch.from_numpy(g['gt']).to(dev), torch.from_numpy(g['es']).to(dev), tol=tol).cpu().numpy()
+        assert np.allclose(got, g[f'rmse_tol{tol}'], rtol=1e-6, atol=0, equal_nan=True)
+    rng = np.random.default_rng(3)
+    gt = np.where(rng.random((500, 6)) < 0.3, 0, rng.uniform(1, 2000, (500, 6))).astype(np.float32)
+    es = np.where(rng.random((500, 9)) < 0.3, 0, gt[:, :1] + rng.normal(0, 1.5, (500, 9))).astype(np.float32)
+    es[7, 2] = np.nan
+    es[8, 1] = np.inf
+    got = toa_rmse(torch.from_numpy(gt).to(dev), torch.from_numpy(es).to(dev), tol=1).cpu().numpy()
+    exp = po.toa_rmse(gt, es, 1)
+    assert np.allclose(got, exp, rtol=1e-5, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize('rf', [10, 20, 1, 2.5])
+def test_iq2rf_matches_numpy_scipy_chain(dev, rf):
+    """datasets/chirp_dataset.py:80-91 + NormalizeVol, float64 oracle (same numpy/scipy calls)."""
+    from stofnet_amd.chirp import iq2rf
+    rng = np.random.default_rng(int(rf * 10))
+    n, ln = 7, 200
+    fs, fc = 2.0e7, 5.2e6
+    env = np.exp(-((np.arange(ln)[None, :] - rng.uniform(40, 160, (n, 1))) / 12.0) ** 2)
+    iq = (env * np.exp(1j * rng.uniform(0, 6.28, (n, 1))) + 0.02 * (rng.standard_normal((n, ln)) + 1j * rng.standard_normal((n, ln))))
+    got = iq2rf(torch.from_numpy(iq.astype(np.complex64)).to(dev), fc, fs, rf).cpu().numpy()
+    exp = po.iq2rf(iq.astype(np.complex64), fc, fs, rf)
+    assert got.shape == exp.shape == (n, int(ln * rf))
+    assert np.abs(got - exp).max() < 1e-5           # max-abs normalised output, fp32 vs float64
+    raw = iq2rf(torch.from_numpy(iq.astype(np.complex64)).to(dev), fc, fs, rf, normalize=False).cpu().numpy()
+    assert np.abs(raw - po.iq2rf(iq.astype(np.complex64), fc, fs, rf, normalize=False)).max() < 1e-5 * np.abs(raw).max() + 1e-6
