@@ -89,6 +89,14 @@ int stof_forward(const stof_net_desc* desc, const void* packed_dev,
                  const float* x, float* y, int64_t N, int64_t L,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same as stof_forward, plus a range guard: bit 0 of *status_dev (a device int32 the caller has
+ * zeroed) is set when the network produced a non-finite output.  In STOF_PREC_F16X3 that is what an
+ * activation beyond the fp16 range (|a| > 65504; trained nets on max-abs-normalised inputs peak
+ * near 50) turns into; the caller can then re-run in STOF_PREC_FP32.  No host sync.             */
+int stof_forward_checked(const stof_net_desc* desc, const void* packed_dev,
+                         const float* x, float* y, int64_t N, int64_t L,
+                         void* workspace, size_t workspace_bytes, void* stream, int32_t* status_dev);
+
 /* Same as stof_forward, with instrumentation for bench.py: `events` is an array of
  * STOF_FORWARD_EVENTS hipEvent_t recorded on `stream` before the first kernel and after each
  * kernel of the first sub-batch (SemiGlobalBlock contract+pool, expand, body sweep), so the

@@ -135,6 +135,7 @@ struct BodyParams {
     const float* chunks;   // [BODY_NCHUNK][BODY_CHUNK_F] fragment-ordered weights
     int N, L, r, P, rem_half, wf_per_wg;
     unsigned long long* stamps;   // diagnostic builds (-DSTOF_STAMPS) only: [wg][wave][8] cycle sums
+    int* status;                  // optional: bit 0 set if a non-finite output was produced (f16x3 range overflow)
 };
 
 template <int S, int RING, int RAWRING>
@@ -492,6 +493,16 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                             store_act4<PREC>(dst + slot[k] * ROWB, 32 * mi + 8 * gg + 4 * lh, v[k][gg]);
                 } else {
                     // conv_last + SampleShuffle1D: out[n][t*r + k] = conv_last[n][k][t]
+                    if (p.status != nullptr) {
+                        // An activation beyond the fp16 range (f16x3 mode) turns into inf/NaN and stays so in
+                        // every output of its receptive field, so checking the last layer alone is enough.
+                        bool bad = false;
+#pragma unroll
+                        for (int k = 0; k < NT; ++k)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) bad = bad || !(fabsf(acc[k][e]) <= 3.0e38f);
+                        if (__any(bad) && lane == 0) atomicOr(p.status, 1);
+                    }
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
                         if (!valid[k]) continue;
@@ -748,7 +759,7 @@ constexpr size_t sgb_lds_bytes() {
 
 template <int PREC>
 int launch_forward(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y, int64_t N,
-                   int64_t L, void* workspace, hipStream_t stream, void* const* events) {
+                   int64_t L, void* workspace, hipStream_t stream, void* const* events, int32_t* status) {
     const int r = desc->upsample_factor;
     const bool has_sgb = desc->semi_global_scale != 1;
     const int64_t P = L / SGB_SCALE;
@@ -813,6 +824,7 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         bp.c1 = c1; bp.bias = bias; bp.chunks = body;
         bp.N = (int)nb; bp.L = (int)L; bp.r = r; bp.P = (int)P; bp.rem_half = (int)(rem / 2);
         bp.stamps = nullptr;
+        bp.status = status;
 #ifdef STOF_STAMPS
         if (workspace) bp.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + (size_t)(nb * P * (NF_SGB + NF)) * sizeof(float) + 256);
 #endif
@@ -829,7 +841,7 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
 }
 
 int forward_impl(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y, int64_t N, int64_t L,
-                 void* workspace, size_t workspace_bytes, void* stream_, void* const* events) {
+                 void* workspace, size_t workspace_bytes, void* stream_, void* const* events, int32_t* status) {
     if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     if (desc->precision != STOF_PREC_FP32 && desc->precision != STOF_PREC_F16X3) return STOF_ERR_UNSUPPORTED;
     const int r = desc->upsample_factor;
@@ -845,8 +857,8 @@ int forward_impl(const stof_net_desc* desc, const void* packed_dev, const float*
         return STOF_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (desc->precision == STOF_PREC_FP32)
-        return launch_forward<STOF_PREC_FP32>(desc, packed_dev, x, y, N, L, workspace, stream, events);
-    return launch_forward<STOF_PREC_F16X3>(desc, packed_dev, x, y, N, L, workspace, stream, events);
+        return launch_forward<STOF_PREC_FP32>(desc, packed_dev, x, y, N, L, workspace, stream, events, status);
+    return launch_forward<STOF_PREC_F16X3>(desc, packed_dev, x, y, N, L, workspace, stream, events, status);
 }
 
 }  // namespace
@@ -864,7 +876,14 @@ extern "C" size_t stof_forward_workspace_bytes(const stof_net_desc* desc, int64_
 
 extern "C" int stof_forward(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,
                             int64_t N, int64_t L, void* workspace, size_t workspace_bytes, void* stream) {
-    return forward_impl(desc, packed_dev, x, y, N, L, workspace, workspace_bytes, stream, nullptr);
+    return forward_impl(desc, packed_dev, x, y, N, L, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int stof_forward_checked(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,
+                                    int64_t N, int64_t L, void* workspace, size_t workspace_bytes, void* stream,
+                                    int32_t* status_dev) {
+    if (!status_dev) return STOF_ERR_BAD_ARG;
+    return forward_impl(desc, packed_dev, x, y, N, L, workspace, workspace_bytes, stream, nullptr, status_dev);
 }
 
 extern "C" int stof_forward_events(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,
@@ -873,7 +892,7 @@ extern "C" int stof_forward_events(const stof_net_desc* desc, const void* packed
     if (!events) return STOF_ERR_BAD_ARG;
     for (int e = 0; e < STOF_FORWARD_EVENTS; ++e)
         if (!events[e]) return STOF_ERR_BAD_ARG;
-    return forward_impl(desc, packed_dev, x, y, N, L, workspace, workspace_bytes, stream, events);
+    return forward_impl(desc, packed_dev, x, y, N, L, workspace, workspace_bytes, stream, events, nullptr);
 }
 
 extern "C" int stof_events_create(int32_t count, void** events_out) {

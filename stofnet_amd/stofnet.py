@@ -71,6 +71,7 @@ class StofNet(nn.Module):
         self._packed = None
         self._packed_key = None
         self._workspace = None
+        self._status = None
 
     # ---- kernel-side state -------------------------------------------------
     def _supported(self):
@@ -130,7 +131,14 @@ class StofNet(nn.Module):
         if self._workspace is None or self._workspace.numel() < ws_bytes or self._workspace.device != x.device:
             self._workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
-            if _events is None:
+            if _events is None and self.precision == 'f16x3':
+                # range guard of the split-fp16 mode: a device-side flag, checked by raise_if_overflow()
+                if self._status is None or self._status.device != x.device:
+                    self._status = torch.zeros(1, dtype=torch.int32, device=x.device)
+                code = lib.stof_forward_checked(ctypes.byref(desc), _lib.ptr(packed), _lib.ptr(xc), _lib.ptr(y), n, L,
+                                                _lib.ptr(self._workspace), self._workspace.numel(),
+                                                _lib.stream_ptr(x.device), _lib.ptr(self._status))
+            elif _events is None:
                 code = lib.stof_forward(ctypes.byref(desc), _lib.ptr(packed), _lib.ptr(xc), _lib.ptr(y), n, L,
                                         _lib.ptr(self._workspace), self._workspace.numel(),
                                         _lib.stream_ptr(x.device))
@@ -145,6 +153,14 @@ class StofNet(nn.Module):
                                f'non-singleton dimension 2')
         _lib.check(code, 'stof_forward')
         return y
+
+    def raise_if_overflow(self):
+        """f16x3 mode only: synchronise and raise if a forward since the last check produced non-finite
+        values (an activation left the fp16 range); re-run such inputs with precision='fp32'."""
+        if self._status is not None and int(self._status.item()) != 0:
+            self._status.zero_()
+            raise FloatingPointError("StofNet(precision='f16x3'): an activation exceeded the fp16 range; "
+                                     "use precision='fp32' for this input")
 
     def _initialize_weights(self):
         """models/stofnet.py:69-77."""

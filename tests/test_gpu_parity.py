@@ -422,3 +422,15 @@ def test_iq2rf_matches_numpy_scipy_chain(dev, rf):
     assert np.abs(got - exp).max() < 1e-5           # max-abs normalised output, fp32 vs float64
     raw = iq2rf(torch.from_numpy(iq.astype(np.complex64)).to(dev), fc, fs, rf, normalize=False).cpu().numpy()
     assert np.abs(raw - po.iq2rf(iq.astype(np.complex64), fc, fs, rf, normalize=False)).max() < 1e-5 * np.abs(raw).max() + 1e-6
+
+
+def test_f16x3_range_guard(dev):
+    m = make_model(dev, synth.synth_state_dict(4, seed=12), 4, precision='f16x3')
+    x = torch.from_numpy(synth.synth_randn(8, 400, seed=5)).to(dev)
+    m(x)
+    m.raise_if_overflow()                                   # normalised input: fine
+    m(x * 3.0e6)                                            # raw, un-normalised amplitudes: beyond fp16
+    with pytest.raises(FloatingPointError):
+        m.raise_if_overflow()
+    m32 = make_model(dev, synth.synth_state_dict(4, seed=12), 4, precision='fp32')
+    assert torch.isfinite(m32(x * 3.0e6)).all()             # the exact mode handles the same input
