@@ -85,7 +85,9 @@ def main(argv=None):
     summary = {'model': name, 'waveforms': int(es_all.shape[0]), 'inference_time': float(np.mean(times)),
                'waveforms_per_s': float(1.0 / np.mean(times))}
     if gt is not None:
-        errs = toa_rmse(torch.from_numpy(gt[:es_all.shape[0]]), torch.from_numpy(es_all), tol=cfg.etol)
+        # toa_rmse (main.py:347) on the device kernel
+        errs = toa_rmse(torch.from_numpy(gt[:es_all.shape[0]]).to(cfg.device), torch.from_numpy(es_all).to(cfg.device),
+                        tol=cfg.etol).cpu()
         summary['total_distance_mean'] = float(np.nanmean(errs[:, 0].numpy()))
         summary['total_jaccard'] = float(np.nanmean(errs[:, 3].numpy()))
     print(json.dumps(summary))

@@ -434,3 +434,22 @@ def test_f16x3_range_guard(dev):
         m.raise_if_overflow()
     m32 = make_model(dev, synth.synth_state_dict(4, seed=12), 4, precision='fp32')
     assert torch.isfinite(m32(x * 3.0e6)).all()             # the exact mode handles the same input
+
+
+def test_main_entry_point_end_to_end(dev, tmp_path):
+    """`python main.py key=value ...` (reference README.md:25 style): config merge, checkpoint lookup by
+    prefix with strict load, forward, mask2coords, device toa_rmse -- against the oracle chain."""
+    import main as entry
+    sd = load_weights('different-armadillo')
+    ck = tmp_path / 'ckpts'
+    ck.mkdir()
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, ck / 'different-armadillo-1439_rf-scale10_epoch_46.pth')
+    es, summary = entry.main(['model=stofnet', 'model_file=different-armadillo_x', 'th=Null', 'evaluate=True',
+                              'batch_size=4', 'num_waveforms=10', 'num_samples=2000', f'ckpt_dir={ck}', 'seed=5'])
+    assert summary['waveforms'] == 8                                      # drop_last=True
+    x = synth.synth_echo(10, 2000, seed=5)[:8]
+    ref = po.mask2coords(so.stofnet_forward(sd, x, 4, 80).numpy(), 20, None, 4)
+    assert np.array_equal(es, ref)
+    es2, s2 = entry.main(['model=gradpeak', 'th=1e-3', 'rf_scale_factor=10', 'batch_size=2', 'num_waveforms=4',
+                          'num_samples=2000', 'seed=5'])
+    assert es2.shape[0] == 4 and s2['model'] == 'gradpeak'
