@@ -27,6 +27,8 @@ class OddSemiGlobalRemainder(RuntimeError):
 
 def _t(a, dtype):
     if isinstance(a, torch.Tensor):
+        if a.requires_grad:                 # oracle/train_oracle.py differentiates through the forward
+            return a.to('cpu', dtype)
         return a.detach().to('cpu', dtype)
     return torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
 

@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libstofnet_amd.so')
-SOURCES = ['pack_weights.cpp', 'convstack.hip', 'shuffle_picker.hip', 'hilbert.hip', 'gradpeak.hip', 'neighbors.hip']
+SOURCES = ['pack_weights.cpp', 'convstack.hip', 'shuffle_picker.hip', 'hilbert.hip', 'gradpeak.hip', 'neighbors.hip', 'train.hip']
 ARCH = 'gfx950'
 
 

@@ -1,0 +1,580 @@
+// Training step building blocks (main.py:204-248), exact fp32.
+//
+// Unlike the fused inference sweep, training keeps every layer's activation in HBM (the backward
+// pass needs them), in channel-last layout [N][L][C] fp32, and runs layer by layer:
+//
+//   conv_cl_kernel        : y = epi( bias + conv_same(x, W) )  -- forward AND data-gradient (dgrad is
+//                           the same convolution with the taps flipped and channels transposed,
+//                           prepared once per step by repack_weights_kernel); MFMA 32x32x2 fp32
+//   conv_wgrad_cl_kernel  : dW[d][o][c] += sum_t dY[t][o] X[t+d-pad][c], db[o] += sum_t dY[t][o]
+//                           (MFMA with the time axis as the reduction dimension, fp32 atomics)
+//   conv1 / pool / upsample / loss / AdamW: small VALU kernels
+//
+// Epilogue `epi` of conv_cl_kernel:  out = act(acc + bias) (+ residual),  or for the backward pass
+// out = (acc (+ residual)) * act'(saved), where act' is read off the sign of the saved activation.
+#include <hip/hip_runtime.h>
+#include "stof_common.h"
+
+using namespace stof;
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int TROWF = 68;                 // LDS row stride (floats) for 64-channel rows, as in the inference kernels
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ __forceinline__ floatx16 mma8(float4 a, float4 b, floatx16 c) {
+    // 8 channels: lane (i, h) holds channels 4h..4h+3 of the group, step s contracts {s, 4+s}
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+
+struct ConvParams {
+    const float* x;        // [N][L][cin]
+    const float* w;        // [K][cout][cin]  (tap-major; for dgrad: flipped taps, transposed channels)
+    const float* bias;     // [cout] or nullptr
+    const float* residual; // [N][L][cout] or nullptr : added after the activation (forward) / before the mask (backward)
+    const float* saved;    // [N][L][cout] or nullptr : backward only, out *= act'(saved)
+    float* y;              // [N][L][cout]
+    int N, L, cin, cout, K, act, tiles_per_wf;
+};
+
+// One work-group: 64 rows x 64 output channels; loops over 64-wide input-channel blocks and taps.
+__global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float xs[(64 + 8) * TROWF];
+    __shared__ __attribute__((aligned(16))) float ws[64 * TROWF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mi = wave & 1, ni = wave >> 1, ln = lane & 31, lh = lane >> 5;
+    const int n = blockIdx.x / p.tiles_per_wf;
+    const int t0 = (blockIdx.x - n * p.tiles_per_wf) * 64;
+    const int o0 = blockIdx.y * 64;
+    const int K = p.K, pad = K >> 1;
+    const int rows = 64 + K - 1;
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    for (int c0 = 0; c0 < p.cin; c0 += 64) {
+        __syncthreads();
+        // activation tile rows t0-pad .. t0+63+pad, channels c0..c0+63 (zero outside the waveform / channel range)
+        for (int i = tid; i < rows * 16; i += 256) {
+            const int r = i >> 4, q = i & 15;
+            const int t = t0 - pad + r, c = c0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < p.L) {
+                const float* src = p.x + ((size_t)n * p.L + t) * p.cin + c;
+                if (c + 3 < p.cin) v = ld4(src);
+                else {
+                    if (c < p.cin) v.x = src[0];
+                    if (c + 1 < p.cin) v.y = src[1];
+                    if (c + 2 < p.cin) v.z = src[2];
+                }
+            }
+            *reinterpret_cast<float4*>(xs + r * TROWF + 4 * q) = v;
+        }
+        for (int d = 0; d < K; ++d) {
+            __syncthreads();
+            for (int i = tid; i < 64 * 16; i += 256) {
+                const int o = i >> 4, q = i & 15;
+                const int c = c0 + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (o0 + o < p.cout) {
+                    const float* src = p.w + ((size_t)d * p.cout + o0 + o) * p.cin + c;
+                    if (c + 3 < p.cin) v = ld4(src);
+                    else {
+                        if (c < p.cin) v.x = src[0];
+                        if (c + 1 < p.cin) v.y = src[1];
+                        if (c + 2 < p.cin) v.z = src[2];
+                    }
+                }
+                *reinterpret_cast<float4*>(ws + o * TROWF + 4 * q) = v;
+            }
+            __syncthreads();
+            const float* arow = ws + (32 * mi + ln) * TROWF + 4 * lh;
+            const float* brow = xs + (32 * ni + ln + d) * TROWF + 4 * lh;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = mma8(ld4(arow + 8 * q), ld4(brow + 8 * q), acc);
+        }
+    }
+    // epilogue: lane (ln, lh) holds time row t0 + 32ni + ln, channels o0 + 32mi + 8gg + 4lh + e
+    const int t = t0 + 32 * ni + ln;
+    if (t >= p.L) return;
+    const size_t rowoff = ((size_t)n * p.L + t) * p.cout;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+        const int o = o0 + 32 * mi + 8 * gg + 4 * lh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (o + e >= p.cout) continue;
+            float v = acc[4 * gg + e];
+            if (p.bias) v += p.bias[o + e];
+            if (p.saved == nullptr) {                       // forward
+                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                if (p.residual) v += p.residual[rowoff + o + e];
+            } else {                                        // backward: (grad + residual grad) * act'(saved)
+                if (p.residual) v += p.residual[rowoff + o + e];
+                const float s = p.saved[rowoff + o + e];
+                if (p.act == ACT_RELU) v = s > 0.f ? v : 0.f;
+                else if (p.act == ACT_LRELU) v = s > 0.f ? v : 0.01f * v;
+            }
+            p.y[rowoff + o + e] = v;
+        }
+    }
+}
+
+// w_out[d][a][b] = w_in[b][a][K-1-d]  (torch layout (cout, cin, K) -> tap-major [K][cin][cout] flipped: dgrad)
+// or w_out[d][o][c] = w_in[o][c][d]   (forward)
+__global__ void repack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int K,
+                                      int transpose_flip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cout * cin * K) return;
+    if (!transpose_flip) {
+        const int c = i % cin, o = (i / cin) % cout, d = i / (cin * cout);
+        out[i] = w[((size_t)o * cin + c) * K + d];
+    } else {
+        const int o = i % cout, c = (i / cout) % cin, d = i / (cin * cout);      // out[d][c][o]
+        out[i] = w[((size_t)o * cin + c) * K + (K - 1 - d)];
+    }
+}
+
+struct WgradParams {
+    const float* x;    // [N][L][cin]
+    const float* dy;   // [N][L][cout]
+    float* dw;         // [cout][cin][K]  (torch layout), accumulated with atomics
+    float* db;         // [cout] or nullptr
+    int N, L, cin, cout, K, tiles_per_wf;
+};
+
+// One work-group: 128 rows of one waveform x (64 output channels) x (64 input channels); each wave
+// owns one 32x32 (o, c) quadrant and all K taps.  Time is the MFMA reduction axis (2 rows / MFMA).
+constexpr int WG_ROWS = 128;
+template <int KMAX>
+__global__ __launch_bounds__(256) void conv_wgrad_cl_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float dys[WG_ROWS * TROWF];
+    __shared__ __attribute__((aligned(16))) float xs[(WG_ROWS + KMAX - 1) * TROWF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mi = wave & 1, ni = wave >> 1, ln = lane & 31, lh = lane >> 5;
+    const int n = blockIdx.x / p.tiles_per_wf;
+    const int t0 = (blockIdx.x - n * p.tiles_per_wf) * WG_ROWS;
+    const int o0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
+    const int K = p.K, pad = K >> 1;
+    for (int i = tid; i < WG_ROWS * 16; i += 256) {
+        const int r = i >> 4, q = i & 15;
+        const int t = t0 + r, o = o0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < p.L) {
+            const float* src = p.dy + ((size_t)n * p.L + t) * p.cout + o;
+            if (o + 3 < p.cout) v = ld4(src);
+            else {
+                if (o < p.cout) v.x = src[0];
+                if (o + 1 < p.cout) v.y = src[1];
+                if (o + 2 < p.cout) v.z = src[2];
+            }
+        }
+        *reinterpret_cast<float4*>(dys + r * TROWF + 4 * q) = v;
+    }
+    for (int i = tid; i < (WG_ROWS + K - 1) * 16; i += 256) {
+        const int r = i >> 4, q = i & 15;
+        const int t = t0 - pad + r, c = c0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < p.L) {
+            const float* src = p.x + ((size_t)n * p.L + t) * p.cin + c;
+            if (c + 3 < p.cin) v = ld4(src);
+            else {
+                if (c < p.cin) v.x = src[0];
+                if (c + 1 < p.cin) v.y = src[1];
+                if (c + 2 < p.cin) v.z = src[2];
+            }
+        }
+        *reinterpret_cast<float4*>(xs + r * TROWF + 4 * q) = v;
+    }
+    __syncthreads();
+    floatx16 acc[KMAX];
+#pragma unroll
+    for (int d = 0; d < KMAX; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+    // A[i = o][k = row parity], B[k][j = c]:  D[o][c] += dY[t][o] * X[t + d - pad][c]
+    const float* ap = dys + lh * TROWF + 32 * mi + ln;
+    const float* bp = xs + lh * TROWF + 32 * ni + ln;
+    for (int r = 0; r < WG_ROWS; r += 2) {
+        const float a = ap[r * TROWF];
+#pragma unroll
+        for (int d = 0; d < KMAX; ++d)
+            if (d < K) acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(r + d) * TROWF], acc[d], 0, 0, 0);
+    }
+    // accumulator register v: row (o) = 32mi + (v&3) + 8(v>>2) + 4lh, col (c) = 32ni + ln
+    const int c = c0 + 32 * ni + ln;
+#pragma unroll
+    for (int d = 0; d < KMAX; ++d) {
+        if (d >= K) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int o = o0 + 32 * mi + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            if (o < p.cout && c < p.cin) atomicAdd(p.dw + ((size_t)o * p.cin + c) * K + d, acc[d][v]);
+        }
+    }
+    if (p.db != nullptr && blockIdx.z == 0 && tid < 64 && o0 + tid < p.cout) {
+        float s = 0.f;
+        for (int r = 0; r < WG_ROWS; ++r) s += dys[r * TROWF + tid];
+        atomicAdd(p.db + o0 + tid, s);
+    }
+}
+
+// conv1 (1 -> 64, k9, pad 4) + ReLU, channel-last output; and its weight gradient
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y, int N, int L) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;      // (n, t, quad of channels)
+    if (i >= (long long)N * L * 16) return;
+    const int q = (int)(i & 15);
+    const long long nt = i >> 4;
+    const int t = (int)(nt % L);
+    const float* xr = x + (nt - t);
+    float xv[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { const int u = t + d - 4; xv[d] = (u >= 0 && u < L) ? xr[u] : 0.f; }
+    float4 o;
+    float* op = &o.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ch = 4 * q + e;
+        float a = b[ch];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) a = fmaf(w[ch * 9 + d], xv[d], a);
+        op[e] = fmaxf(a, 0.f);
+    }
+    *reinterpret_cast<float4*>(y + nt * 64 + 4 * q) = o;
+}
+
+// dW1[ch][d] += sum_t g'[t][ch] x[t+d-4], db1[ch] += sum_t g'[t][ch], g' = g * relu'(saved conv1 output)
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ saved, float* __restrict__ dw,
+                                                          float* __restrict__ db, int N, int L, int rows_per_block) {
+    __shared__ float red[4][64][10];
+    const int tid = threadIdx.x, ch = tid & 63, part = tid >> 6;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    float acc[10];
+#pragma unroll
+    for (int d = 0; d < 10; ++d) acc[d] = 0.f;
+    for (long long r = r0 + part; r < r0 + rows_per_block && r < (long long)N * L; r += 4) {
+        const int t = (int)(r % L);
+        const float* xr = x + (r - t);
+        const float gv = saved[r * 64 + ch] > 0.f ? g[r * 64 + ch] : 0.f;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) { const int u = t + d - 4; acc[d] = fmaf(gv, (u >= 0 && u < L) ? xr[u] : 0.f, acc[d]); }
+        acc[9] += gv;
+    }
+#pragma unroll
+    for (int d = 0; d < 10; ++d) red[part][ch][d] = acc[d];
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+        for (int d = 0; d < 10; ++d) {
+            const float s = (red[0][ch][d] + red[1][ch][d]) + (red[2][ch][d] + red[3][ch][d]);
+            if (d < 9) atomicAdd(dw + ch * 9 + d, s); else atomicAdd(db + ch, s);
+        }
+    }
+}
+
+// MaxPool1d(80, 80) over time of c[N][L][C] -> pooled[N][P][C] with the arg-max offset (first maximum)
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ c, float* __restrict__ pooled,
+                                                       unsigned char* __restrict__ arg, int N, int L, int P, int C) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;      // (n, w, ch)
+    if (i >= (long long)N * P * C) return;
+    const int ch = (int)(i % C);
+    const long long nw = i / C;
+    const int w = (int)(nw % P);
+    const long long n = nw / P;
+    const float* src = c + (n * L + (long long)w * SGB_SCALE) * C + ch;
+    float best = src[0];
+    int bi = 0;
+    for (int k = 1; k < SGB_SCALE; ++k) {
+        const float v = src[(long long)k * C];
+        if (v > best) { best = v; bi = k; }
+    }
+    pooled[i] = best;
+    arg[i] = (unsigned char)bi;
+}
+
+// gc[N][L][C] = 0 except gc[n][80w + arg][ch] = gpool[n][w][ch] * lrelu'(c at that position)
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ gpool, const unsigned char* __restrict__ arg,
+                                                       const float* __restrict__ c, float* __restrict__ gc,
+                                                       int N, int L, int P, int C) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= (long long)N * P * C) return;
+    const int ch = (int)(i % C);
+    const long long nw = i / C;
+    const int w = (int)(nw % P);
+    const long long n = nw / P;
+    const long long pos = (n * L + (long long)w * SGB_SCALE + arg[i]) * C + ch;
+    const float s = c[pos];
+    gc[pos] = s > 0.f ? gpool[i] : 0.01f * gpool[i];
+}
+
+// x0[n][t][ch] = a[n][t][ch] + e[n][w(t)][ch]   (nearest upsample x80, shifted by rem_half, zero outside)
+__global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restrict__ a, const float* __restrict__ e,
+                                                           float* __restrict__ out, int N, int L, int P, int rem_half) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;      // float4 index
+    if (i >= (long long)N * L * 16) return;
+    const int q = (int)(i & 15);
+    const long long nt = i >> 4;
+    const int t = (int)(nt % L);
+    const long long n = nt / L;
+    float4 v = ld4(a + nt * 64 + 4 * q);
+    const int pos = t - rem_half;
+    if (pos >= 0 && pos < SGB_SCALE * P) {
+        const float4 s = ld4(e + (n * P + pos / SGB_SCALE) * 64 + 4 * q);
+        v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+    }
+    *reinterpret_cast<float4*>(out + nt * 64 + 4 * q) = v;
+}
+
+// ge[n][w][ch] = lrelu'(e) * sum_{t in window w} g[n][t][ch]
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ g, const float* __restrict__ e,
+                                                           float* __restrict__ ge, int N, int L, int P, int rem_half) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;      // (n, w, ch)
+    if (i >= (long long)N * P * 64) return;
+    const int ch = (int)(i & 63);
+    const long long nw = i >> 6;
+    const int w = (int)(nw % P);
+    const long long n = nw / P;
+    const float* src = g + (n * L + rem_half + (long long)w * SGB_SCALE) * 64 + ch;
+    float s = 0.f;
+    for (int k = 0; k < SGB_SCALE; ++k) s += src[(long long)k * 64];
+    ge[i] = e[i] > 0.f ? s : 0.01f * s;
+}
+
+// ---- loss (main.py:228-232): target = 20 * blur7(onehot(gt)) / max(blur); MSE + lambda * mean|pred|
+__global__ __launch_bounds__(256) void loss_target_kernel(const long long* __restrict__ gt, int G, const float* __restrict__ taps,
+                                                          float* __restrict__ target, int N, int M, float* __restrict__ tmax) {
+    // one block per row: scatter ones (index 0 cleared, negatives clamped: coords2mask), 7-tap blur with zero padding
+    extern __shared__ float mask[];
+    const int tid = threadIdx.x;
+    const long long row = blockIdx.x;
+    for (int i = tid; i < M; i += 256) mask[i] = 0.f;
+    __syncthreads();
+    for (int k = tid; k < G; k += 256) {
+        long long idx = gt[row * G + k];
+        if (idx < 0) idx = 0;
+        if (idx < M) mask[idx] = 1.f;
+    }
+    __syncthreads();
+    if (tid == 0) mask[0] = 0.f;
+    __syncthreads();
+    float mx = 0.f;
+    for (int i = tid; i < M; i += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) { const int u = i + d - 3; if (u >= 0 && u < M) s = fmaf(taps[d], mask[u], s); }
+        target[row * M + i] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) atomicMax(reinterpret_cast<int*>(tmax), __float_as_int(mx));   // mx >= 0: int order = float order
+}
+
+// loss[0] += sum (pred - s*target)^2 / NM + lambda * sum |pred| / NM ; dpred = 2 (pred - s*target)/NM + lambda sign(pred)/NM
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        const float* __restrict__ tmax, float amplitude, float lambda,
+                                                        long long count, float* __restrict__ dpred, double* __restrict__ loss) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    const float scale = amplitude / tmax[0];
+    const double inv = 1.0 / (double)count;
+    double part = 0.0;
+    if (i < count) {
+        const float pv = pred[i];
+        const float diff = pv - target[i] * scale;
+        part = ((double)diff * diff + (double)lambda * fabsf(pv)) * inv;
+        const float sg = pv > 0.f ? 1.f : (pv < 0.f ? -1.f : 0.f);
+        dpred[i] = (float)((2.0 * diff + (double)lambda * sg) * inv);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss, part);
+}
+
+// torch.optim.AdamW step (decoupled weight decay), one flat parameter vector
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, float lr, float beta1, float beta2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= n) return;
+    float pv = p[i];
+    const float gv = g[i];
+    pv *= 1.f - lr * wd;
+    const float mv = beta1 * m[i] + (1.f - beta1) * gv;
+    const float vv = beta2 * v[i] + (1.f - beta2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = pv - (lr / bc1) * (mv / denom);
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long long n) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" int stof_train_conv(const float* x, const float* w_tapmajor, const float* bias, const float* residual,
+                               const float* saved, float* y, int64_t N, int64_t L, int32_t cin, int32_t cout,
+                               int32_t K, int32_t act, void* stream) {
+    if (N < 0 || L < 0 || cin < 1 || cout < 1 || K < 1 || K > 9 || !(K & 1)) return STOF_ERR_BAD_ARG;
+    if (N == 0 || L == 0) return STOF_OK;
+    if (!x || !w_tapmajor || !y) return STOF_ERR_BAD_ARG;
+    ConvParams p;
+    p.x = x; p.w = w_tapmajor; p.bias = bias; p.residual = residual; p.saved = saved; p.y = y;
+    p.N = (int)N; p.L = (int)L; p.cin = cin; p.cout = cout; p.K = K; p.act = act;
+    p.tiles_per_wf = (int)((L + 63) / 64);
+    const int64_t gx = N * p.tiles_per_wf;
+    if (gx > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_cl_kernel, dim3((unsigned)gx, (unsigned)((cout + 63) / 64)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_repack(const float* w, float* out, int32_t cout, int32_t cin, int32_t K, int32_t transpose_flip,
+                                 void* stream) {
+    if (!w || !out || cout < 1 || cin < 1 || K < 1) return STOF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(repack_weights_kernel, dim3(blocks_for((long long)cout * cin * K)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, out, cout, cin, K, transpose_flip);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_wgrad(const float* x, const float* dy, float* dw, float* db, int64_t N, int64_t L,
+                                int32_t cin, int32_t cout, int32_t K, void* stream) {
+    if (N < 0 || L < 0 || cin < 1 || cout < 1 || K < 1 || K > 7 || !(K & 1)) return STOF_ERR_BAD_ARG;
+    if (N == 0 || L == 0) return STOF_OK;
+    if (!x || !dy || !dw) return STOF_ERR_BAD_ARG;
+    WgradParams p;
+    p.x = x; p.dy = dy; p.dw = dw; p.db = db; p.N = (int)N; p.L = (int)L; p.cin = cin; p.cout = cout; p.K = K;
+    p.tiles_per_wf = (int)((L + WG_ROWS - 1) / WG_ROWS);
+    const int64_t gx = N * p.tiles_per_wf;
+    if (gx > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)gx, (unsigned)((cout + 63) / 64), (unsigned)((cin + 63) / 64));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (K <= 3) hipLaunchKernelGGL(conv_wgrad_cl_kernel<3>, grid, dim3(256), 0, s, p);
+    else if (K <= 5) hipLaunchKernelGGL(conv_wgrad_cl_kernel<5>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_wgrad_cl_kernel<7>, grid, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_conv1(const float* x, const float* w, const float* b, float* y, int64_t N, int64_t L, void* stream) {
+    if (N < 0 || L < 0) return STOF_ERR_BAD_ARG;
+    if (N == 0 || L == 0) return STOF_OK;
+    if (!x || !w || !b || !y) return STOF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks_for(N * L * 16)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, w, b, y, (int)N, (int)L);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_conv1_wgrad(const float* x, const float* g, const float* saved, float* dw, float* db, int64_t N,
+                                      int64_t L, void* stream) {
+    if (N < 0 || L < 0) return STOF_ERR_BAD_ARG;
+    if (N == 0 || L == 0) return STOF_OK;
+    if (!x || !g || !saved || !dw || !db) return STOF_ERR_BAD_ARG;
+    const int rows_per_block = 512;
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)((N * L + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, g, saved, dw, db, (int)N, (int)L, rows_per_block);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_pool(const float* c, float* pooled, uint8_t* arg, int64_t N, int64_t L, int64_t P, int32_t C,
+                               void* stream) {
+    if (N < 0 || L < 0 || P < 0 || C < 1 || P * SGB_SCALE > L) return STOF_ERR_BAD_ARG;
+    if (N * P == 0) return STOF_OK;
+    if (!c || !pooled || !arg) return STOF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(blocks_for(N * P * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       c, pooled, arg, (int)N, (int)L, (int)P, C);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_pool_bwd(const float* gpool, const uint8_t* arg, const float* c, float* gc, int64_t N, int64_t L,
+                                   int64_t P, int32_t C, void* stream) {
+    if (N < 0 || L < 0 || P < 0 || C < 1) return STOF_ERR_BAD_ARG;
+    if (N * L == 0) return STOF_OK;
+    if (!gpool || !arg || !c || !gc) return STOF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(gc, 0, (size_t)N * L * C * sizeof(float), s) != hipSuccess) return STOF_ERR_HIP;
+    if (N * P > 0)
+        hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for(N * P * C)), dim3(256), 0, s, gpool, arg, c, gc, (int)N, (int)L,
+                           (int)P, C);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_upsample_add(const float* a, const float* e, float* out, int64_t N, int64_t L, int64_t P,
+                                       int32_t rem_half, void* stream) {
+    if (N < 0 || L < 0 || P < 0) return STOF_ERR_BAD_ARG;
+    if (N * L == 0) return STOF_OK;
+    if (!a || !out || (!e && P > 0)) return STOF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks_for(N * L * 16)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       a, e, out, (int)N, (int)L, (int)P, rem_half);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_upsample_bwd(const float* g, const float* e, float* ge, int64_t N, int64_t L, int64_t P,
+                                       int32_t rem_half, void* stream) {
+    if (N < 0 || L < 0 || P < 0) return STOF_ERR_BAD_ARG;
+    if (N * P == 0) return STOF_OK;
+    if (!g || !e || !ge) return STOF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(blocks_for(N * P * 64)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       g, e, ge, (int)N, (int)L, (int)P, rem_half);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+// scratch: tmax[1] float (zeroed here), target[N*M]; loss[1] double (zeroed here)
+extern "C" int stof_train_loss(const float* pred, const int64_t* gt_idx, int64_t G, const float* taps7, int64_t N, int64_t M,
+                               float amplitude, float lambda, float* target, float* tmax, float* dpred, double* loss,
+                               void* stream) {
+    if (N < 0 || M < 0 || G < 0) return STOF_ERR_BAD_ARG;
+    if (N * M == 0) return STOF_OK;
+    if (!pred || !gt_idx || !taps7 || !target || !tmax || !dpred || !loss) return STOF_ERR_BAD_ARG;
+    if ((size_t)M * sizeof(float) > 160 * 1024) return STOF_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(tmax, 0, sizeof(float), s) != hipSuccess || hipMemsetAsync(loss, 0, sizeof(double), s) != hipSuccess)
+        return STOF_ERR_HIP;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_target_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) return STOF_ERR_HIP;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(loss_target_kernel, dim3((unsigned)N), dim3(256), (size_t)M * sizeof(float), s,
+                       reinterpret_cast<const long long*>(gt_idx), (int)G, taps7, target, (int)N, (int)M, tmax);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(blocks_for(N * M)), dim3(256), 0, s, pred, target, tmax, amplitude, lambda,
+                       (long long)(N * M), dpred, loss);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream) {
+    if (n < 0 || step < 1) return STOF_ERR_BAD_ARG;
+    if (n == 0) return STOF_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq) return STOF_ERR_BAD_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), params, grads,
+                       exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (n < 0) return STOF_ERR_BAD_ARG;
+    if (n == 0) return STOF_OK;
+    if (!a || !b || !out) return STOF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, (long long)n);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}

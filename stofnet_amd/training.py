@@ -1,0 +1,212 @@
+"""Training step of StofNet on the gfx950 kernels (reference
+main.py:204-248): forward with saved activations, the Gaussian-mask loss, the full backward pass,
+AdamW, and the DDP-style gradient all-reduce (one flat 2.58 MB bucket over RCCL).
+
+Everything numerical runs in `stofnet_amd/csrc/train.hip` through the C ABI, exact fp32, layer by
+layer on channel-last [N][L][C] activations (the backward pass needs every layer's activation, so
+the fused inference sweep does not apply).  PyTorch only owns the device buffers.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .stofnet import StofNet
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+
+
+def gaussian_kernel(size, sigma=1.0):
+    """utils/gaussian.py:4-7."""
+    x = np.linspace(-size // 2 + 1, size // 2, size)
+    k = np.exp(-np.power(x / sigma, 2) / 2)
+    return k / np.sum(k)
+
+
+class StofNetTrainer:
+    """AdamW(lr, weight_decay) + MSE(pred, 20*blur7(onehot(gt))/max) + lambda*mean|pred| on `model`
+    (main.py:179,184-188,228-232,246-248).  The model's parameters are re-seated as views of one flat
+    buffer so the optimizer kernel and the gradient all-reduce touch a single tensor."""
+
+    def __init__(self, model: StofNet, lr=5e-4, weight_decay=1e-8, lambda_value=1e-2, mask_amplitude=20,
+                 kernel_size=7, sigma=1, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        if not model._supported():
+            raise NotImplementedError('only the shipped StofNet architecture is supported')
+        if kernel_size != 7:
+            raise NotImplementedError('the loss kernel implements the 7-tap blur of config.yaml:23')
+        self.model = model
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
+        self.lam, self.amp = float(lambda_value), float(mask_amplitude)
+        self.group = process_group
+        self.step_count = 0
+        params = list(model.named_parameters())
+        dev = params[0][1].device
+        _lib.require_device(params[0][1], 'model parameters')
+        self.names = [n for n, _ in params]
+        sizes = [p.numel() for _, p in params]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros_like(self.flat)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.p, self.g = {}, {}
+        off = 0
+        for (name, prm), n in zip(params, sizes):
+            view = self.flat[off:off + n].view(prm.shape)
+            view.copy_(prm.data)
+            prm.data = view                                   # the module now lives in the flat buffer
+            self.p[name] = view
+            self.g[name] = self.flat_grad[off:off + n].view(prm.shape)
+            off += n
+        self.taps = torch.tensor(gaussian_kernel(kernel_size, sigma), dtype=torch.float32, device=dev)
+        self.dev = dev
+        self.r = int(model.upsample_factor)
+        self.sgb = model.semi_global_block is not None
+
+    # ---- thin wrappers over the C ABI ---------------------------------------------------------
+    def _st(self):
+        return _lib.stream_ptr(self.dev)
+
+    def _conv(self, x, w_tm, bias, cin, cout, K, act=ACT_NONE, residual=None, saved=None):
+        n, L = x.shape[0], x.shape[1]
+        y = torch.empty((n, L, cout), dtype=torch.float32, device=self.dev)
+        _lib.check(_lib.lib().stof_train_conv(_lib.ptr(x), _lib.ptr(w_tm), _lib.ptr(bias), _lib.ptr(residual),
+                                              _lib.ptr(saved), _lib.ptr(y), n, L, cin, cout, K, act, self._st()),
+                   'stof_train_conv')
+        return y
+
+    def _repack(self, w, flip):
+        cout, cin, K = w.shape
+        out = torch.empty(w.numel(), dtype=torch.float32, device=self.dev)
+        _lib.check(_lib.lib().stof_train_repack(_lib.ptr(w), _lib.ptr(out), cout, cin, K, 1 if flip else 0, self._st()),
+                   'stof_train_repack')
+        return out
+
+    def _wgrad(self, x, dy, name, cin, cout, K):
+        n, L = x.shape[0], x.shape[1]
+        _lib.check(_lib.lib().stof_train_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(self.g[name + '.weight']),
+                                               _lib.ptr(self.g[name + '.bias']), n, L, cin, cout, K, self._st()),
+                   'stof_train_wgrad')
+
+    def _add(self, a, b):
+        out = torch.empty_like(a)
+        _lib.check(_lib.lib().stof_train_add(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), self._st()), 'stof_train_add')
+        return out
+
+    # ---- forward + loss + backward -----------------------------------------------------------
+    def forward_backward(self, frame: torch.Tensor, gt_true: torch.Tensor):
+        """frame [N,1,L] fp32, gt_true [N,1,G] int64 (round(gt_sample * r), main.py:218).  Fills the
+        gradient buffer and returns (loss as a 0-d float64 device tensor, masks_pred [N,1,L*r])."""
+        lib = _lib.lib()
+        _lib.require_device(frame, 'frame')
+        p, r = self.p, self.r
+        x = frame.detach().reshape(frame.shape[0], frame.shape[-1]).contiguous().float()
+        n, L = x.shape
+        P = L // 80 if self.sgb else 0
+        rem = L - 80 * P
+        if self.sgb and rem % 2:
+            raise RuntimeError(f'The size of tensor a ({L}) must match the size of tensor b ({L - 1}) at non-singleton dimension 2')
+        with torch.cuda.device(self.dev):
+            st = self._st()
+            self.flat_grad.zero_()
+            fwd = {k[:-7]: self._repack(v, False) for k, v in p.items() if k.endswith('.weight') and k != 'conv1.weight'}
+            bwd = {k[:-7]: self._repack(v, True) for k, v in p.items() if k.endswith('.weight') and k != 'conv1.weight'}
+            # ---------------- forward (models/stofnet.py:42-67), activations kept
+            a1 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
+            _lib.check(lib.stof_train_conv1(_lib.ptr(x), _lib.ptr(p['conv1.weight']), _lib.ptr(p['conv1.bias']), _lib.ptr(a1),
+                                            n, L, st), 'stof_train_conv1')
+            if self.sgb:
+                sg = 'semi_global_block.'
+                c = self._conv(a1, fwd[sg + 'contract_conv'], p[sg + 'contract_conv.bias'], 64, 512, 5, ACT_LRELU)
+                pooled = torch.empty((n, max(P, 1), 512), dtype=torch.float32, device=self.dev)[:, :P]
+                arg = torch.empty((n, max(P, 1), 512), dtype=torch.uint8, device=self.dev)[:, :P]
+                _lib.check(lib.stof_train_pool(_lib.ptr(c), _lib.ptr(pooled), _lib.ptr(arg), n, L, P, 512, st), 'stof_train_pool')
+                e = self._conv(pooled, fwd[sg + 'expand_conv'], p[sg + 'expand_conv.bias'], 512, 64, 5, ACT_LRELU) if P else pooled[..., :64]
+                x0 = torch.empty_like(a1)
+                _lib.check(lib.stof_train_upsample_add(_lib.ptr(a1), _lib.ptr(e), _lib.ptr(x0), n, L, P, rem // 2, st),
+                           'stof_train_upsample_add')
+            else:
+                x0 = a1
+            xs, ys = [x0], []
+            for k in range(5):
+                ys.append(self._conv(xs[-1], fwd[f'conv{2 * k + 2}'], p[f'conv{2 * k + 2}.bias'], 64, 64, 7, ACT_LRELU))
+                xs.append(self._conv(ys[-1], fwd[f'conv{2 * k + 3}'], p[f'conv{2 * k + 3}.bias'], 64, 64, 7, ACT_NONE, residual=xs[-1]))
+            x6 = self._conv(xs[5], fwd['conv12'], p['conv12.bias'], 64, 64, 7, ACT_NONE, residual=x0)
+            z = self._conv(x6, fwd['conv_last'], p['conv_last.bias'], 64, r, 3, ACT_NONE)      # [N, L, r] == shuffled [N, L*r]
+            pred = z.view(n, L * r)
+            # ---------------- loss (main.py:228-232)
+            gt = gt_true.detach().reshape(n, -1).contiguous().to(self.dev, torch.int64)
+            target = torch.empty_like(pred)
+            dpred = torch.empty_like(pred)
+            tmax = torch.empty(1, dtype=torch.float32, device=self.dev)
+            loss = torch.empty(1, dtype=torch.float64, device=self.dev)
+            _lib.check(lib.stof_train_loss(_lib.ptr(pred), _lib.ptr(gt), gt.shape[1], _lib.ptr(self.taps), n, L * r, self.amp,
+                                           self.lam, _lib.ptr(target), _lib.ptr(tmax), _lib.ptr(dpred), _lib.ptr(loss), st),
+                       'stof_train_loss')
+            # ---------------- backward
+            dz = dpred.view(n, L, r)
+            self._wgrad(x6, dz, 'conv_last', 64, r, 3)
+            g6 = self._conv(dz, bwd['conv_last'], None, r, 64, 3)
+            self._wgrad(xs[5], g6, 'conv12', 64, 64, 7)
+            g = self._conv(g6, bwd['conv12'], None, 64, 64, 7)                       # d/dx5
+            for k in range(4, -1, -1):
+                nb, na = f'conv{2 * k + 3}', f'conv{2 * k + 2}'
+                self._wgrad(ys[k], g, nb, 64, 64, 7)
+                u = self._conv(g, bwd[nb], None, 64, 64, 7, ACT_LRELU, saved=ys[k])  # d/d(pre-activation of conv_a)
+                self._wgrad(xs[k], u, na, 64, 64, 7)
+                g = self._conv(u, bwd[na], None, 64, 64, 7, residual=g)              # d/dx_k
+            g_x0 = self._add(g, g6)                                                  # long skip res1 (models/stofnet.py:62)
+            if self.sgb and P:
+                ge = torch.empty((n, P, 64), dtype=torch.float32, device=self.dev)
+                _lib.check(lib.stof_train_upsample_bwd(_lib.ptr(g_x0), _lib.ptr(e), _lib.ptr(ge), n, L, P, rem // 2, st),
+                           'stof_train_upsample_bwd')
+                self._wgrad(pooled, ge, sg + 'expand_conv', 512, 64, 5)
+                gpool = self._conv(ge, bwd[sg + 'expand_conv'], None, 64, 512, 5)
+                gc = torch.empty_like(c)
+                _lib.check(lib.stof_train_pool_bwd(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(c), _lib.ptr(gc), n, L, P, 512, st),
+                           'stof_train_pool_bwd')
+                self._wgrad(a1, gc, sg + 'contract_conv', 64, 512, 5)
+                g_a1 = self._conv(gc, bwd[sg + 'contract_conv'], None, 512, 64, 5, residual=g_x0)
+            else:
+                g_a1 = g_x0
+            _lib.check(lib.stof_train_conv1_wgrad(_lib.ptr(x), _lib.ptr(g_a1), _lib.ptr(a1), _lib.ptr(self.g['conv1.weight']),
+                                                  _lib.ptr(self.g['conv1.bias']), n, L, st), 'stof_train_conv1_wgrad')
+        return loss[0], pred.view(n, 1, L * r)
+
+    def allreduce_grads(self):
+        """DDP semantics: average the flat gradient bucket over the process group (RCCL over xGMI on the
+        GPU node; one 2.58 MB all-reduce per step, latency-bound)."""
+        allreduce_mean_(self.flat_grad, self.group)
+
+    def step(self):
+        self.step_count += 1
+        with torch.cuda.device(self.dev):
+            _lib.check(_lib.lib().stof_train_adamw(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
+                                                   _lib.ptr(self.exp_avg_sq), self.flat.numel(), self.lr, self.betas[0],
+                                                   self.betas[1], self.eps, self.wd, self.step_count, self._st()),
+                       'stof_train_adamw')
+        self.model._packed = None                              # inference weights must be repacked
+
+    def train_step(self, frame, gt_true):
+        loss, pred = self.forward_backward(frame, gt_true)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            self.allreduce_grads()
+        self.step()
+        return loss, pred
+
+    def set_lr_cosine(self, epoch, epochs, base_lr):
+        """CosineAnnealingLR(optimizer, epochs) stepped once per epoch (main.py:180,288)."""
+        self.lr = 0.5 * base_lr * (1.0 + math.cos(math.pi * epoch / epochs))
+
+
+def allreduce_mean_(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place mean all-reduce of a flat gradient bucket (works on any backend: nccl = RCCL, gloo in tests)."""
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        if world > 1:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+            flat_grad.div_(world)
+    return flat_grad
