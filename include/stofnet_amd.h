@@ -192,9 +192,11 @@ int stof_train_repack(const float* w, float* out, int32_t cout, int32_t cin, int
 int stof_train_conv(const float* x, const float* w_tapmajor, const float* bias, const float* residual,
                     const float* saved, float* y, int64_t N, int64_t L, int32_t cin, int32_t cout,
                     int32_t K, int32_t act, void* stream);
-/* dw (cout,cin,K) += sum_t dy[t][o] x[t+d-pad][c];  db[cout] += sum_t dy[t][o]  (db may be NULL).   */
+/* dw (cout,cin,K) = sum_t dy[t][o] x[t+d-pad][c];  db[cout] = sum_t dy[t][o]  (db may be NULL).  Overwrites
+ * dw/db; partial sums go through `workspace` and are added in a fixed order (bitwise reproducible).   */
+size_t stof_train_wgrad_workspace_bytes(int32_t cin, int32_t cout, int32_t K);
 int stof_train_wgrad(const float* x, const float* dy, float* dw, float* db, int64_t N, int64_t L,
-                     int32_t cin, int32_t cout, int32_t K, void* stream);
+                     int32_t cin, int32_t cout, int32_t K, void* workspace, size_t workspace_bytes, void* stream);
 /* conv1 (1->64, k9) + ReLU forward to channel-last, and its weight gradient (g masked by relu').    */
 int stof_train_conv1(const float* x, const float* w, const float* b, float* y, int64_t N, int64_t L, void* stream);
 int stof_train_conv1_wgrad(const float* x, const float* g, const float* saved, float* dw, float* db,

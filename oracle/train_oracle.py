@@ -26,4 +26,4 @@ def loss_and_grads(params, x, gt_true, r, sgs=80, dtype=torch.float64, **kw):
     pred = so.stofnet_forward(p, torch.tensor(np.asarray(x), dtype=dtype), r, sgs, dtype)
     loss = loss_fn(pred, torch.as_tensor(gt_true), **kw)
     grads = torch.autograd.grad(loss, list(p.values()))
-    return float(loss), {k: g.numpy() for k, g in zip(p.keys(), grads)}, pred.detach().numpy()
+    return float(loss.detach()), {k: g.numpy() for k, g in zip(p.keys(), grads)}, pred.detach().numpy()

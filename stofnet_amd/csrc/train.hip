@@ -46,30 +46,38 @@ struct ConvParams {
     int N, L, cin, cout, K, act, tiles_per_wf;
 };
 
-// One work-group: 64 rows x 64 output channels; loops over 64-wide input-channel blocks and taps.
+// One work-group: CT = 128 time rows x 64 output channels; loops over 64-wide input-channel blocks and
+// taps.  Wave (mi, ni): output-channel half mi, time rows 64ni..64ni+63 as two 32-row MFMA tiles that share
+// the weight fragments.  The weight tile of the next (block, tap) step is fetched from L2 into registers
+// while the MFMAs of the current one run, and lands in the other half of a double-buffered LDS tile.
+constexpr int CT = 128;
 __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
-    __shared__ __attribute__((aligned(16))) float xs[(64 + 8) * TROWF];
-    __shared__ __attribute__((aligned(16))) float ws[64 * TROWF];
+    __shared__ __attribute__((aligned(16))) float xs[(CT + 8) * TROWF];
+    __shared__ __attribute__((aligned(16))) float ws[2][64 * TROWF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mi = wave & 1, ni = wave >> 1, ln = lane & 31, lh = lane >> 5;
     const int n = blockIdx.x / p.tiles_per_wf;
-    const int t0 = (blockIdx.x - n * p.tiles_per_wf) * 64;
+    const int t0 = (blockIdx.x - n * p.tiles_per_wf) * CT;
     const int o0 = blockIdx.y * 64;
     const int K = p.K, pad = K >> 1;
-    const int rows = 64 + K - 1;
-    floatx16 acc;
+    const int rows = CT + K - 1;
+    const int nsteps = ((p.cin + 63) >> 6) * K;
+    floatx16 acc[2];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-    for (int c0 = 0; c0 < p.cin; c0 += 64) {
-        __syncthreads();
-        // activation tile rows t0-pad .. t0+63+pad, channels c0..c0+63 (zero outside the waveform / channel range)
-        for (int i = tid; i < rows * 16; i += 256) {
-            const int r = i >> 4, q = i & 15;
-            const int t = t0 - pad + r, c = c0 + 4 * q;
+    float4 wreg[4];
+    auto wfetch = [&](int s) {
+        const int c0 = (s / K) << 6, d = s - (s / K) * K;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, o = i >> 4, q = i & 15;
+            const int c = c0 + 4 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < p.L) {
-                const float* src = p.x + ((size_t)n * p.L + t) * p.cin + c;
+            if (o0 + o < p.cout) {
+                const float* src = p.w + ((size_t)d * p.cout + o0 + o) * p.cin + c;
                 if (c + 3 < p.cin) v = ld4(src);
                 else {
                     if (c < p.cin) v.x = src[0];
@@ -77,16 +85,22 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
                     if (c + 2 < p.cin) v.z = src[2];
                 }
             }
-            *reinterpret_cast<float4*>(xs + r * TROWF + 4 * q) = v;
+            wreg[u] = v;
         }
-        for (int d = 0; d < K; ++d) {
+    };
+    wfetch(0);
+    for (int s = 0; s < nsteps; ++s) {
+        const int cb = s / K, d = s - cb * K;
+        if (d == 0) {
+            // activation tile rows t0-pad .. t0+CT-1+pad, channels 64cb.. (zero outside the waveform / channel range)
             __syncthreads();
-            for (int i = tid; i < 64 * 16; i += 256) {
-                const int o = i >> 4, q = i & 15;
-                const int c = c0 + 4 * q;
+            const int c0 = cb << 6;
+            for (int i = tid; i < rows * 16; i += 256) {
+                const int r = i >> 4, q = i & 15;
+                const int t = t0 - pad + r, c = c0 + 4 * q;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (o0 + o < p.cout) {
-                    const float* src = p.w + ((size_t)d * p.cout + o0 + o) * p.cin + c;
+                if (t >= 0 && t < p.L) {
+                    const float* src = p.x + ((size_t)n * p.L + t) * p.cin + c;
                     if (c + 3 < p.cin) v = ld4(src);
                     else {
                         if (c < p.cin) v.x = src[0];
@@ -94,38 +108,71 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
                         if (c + 2 < p.cin) v.z = src[2];
                     }
                 }
-                *reinterpret_cast<float4*>(ws + o * TROWF + 4 * q) = v;
+                *reinterpret_cast<float4*>(xs + r * TROWF + 4 * q) = v;
             }
-            __syncthreads();
-            const float* arow = ws + (32 * mi + ln) * TROWF + 4 * lh;
-            const float* brow = xs + (32 * ni + ln + d) * TROWF + 4 * lh;
+        }
+        float* wb = ws[s & 1];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc = mma8(ld4(arow + 8 * q), ld4(brow + 8 * q), acc);
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u;
+            *reinterpret_cast<float4*>(wb + (i >> 4) * TROWF + 4 * (i & 15)) = wreg[u];
+        }
+        __syncthreads();
+        if (s + 1 < nsteps) wfetch(s + 1);
+        const float* arow = wb + (32 * mi + ln) * TROWF + 4 * lh;
+        const float* brow = xs + (64 * ni + ln + d) * TROWF + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 a = ld4(arow + 8 * q);
+            acc[0] = mma8(a, ld4(brow + 8 * q), acc[0]);
+            acc[1] = mma8(a, ld4(brow + 32 * TROWF + 8 * q), acc[1]);
         }
     }
-    // epilogue: lane (ln, lh) holds time row t0 + 32ni + ln, channels o0 + 32mi + 8gg + 4lh + e
-    const int t = t0 + 32 * ni + ln;
-    if (t >= p.L) return;
-    const size_t rowoff = ((size_t)n * p.L + t) * p.cout;
+    // epilogue: lane (ln, lh) holds time row t0 + 64ni + 32j + ln, channels o0 + 32mi + 8gg + 4lh + e
+    const bool vec = (p.cout & 3) == 0;
 #pragma unroll
-    for (int gg = 0; gg < 4; ++gg) {
-        const int o = o0 + 32 * mi + 8 * gg + 4 * lh;
+    for (int j = 0; j < 2; ++j) {
+        const int t = t0 + 64 * ni + 32 * j + ln;
+        if (t >= p.L) continue;
+        const size_t rowoff = ((size_t)n * p.L + t) * p.cout;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (o + e >= p.cout) continue;
-            float v = acc[4 * gg + e];
-            if (p.bias) v += p.bias[o + e];
-            if (p.saved == nullptr) {                       // forward
-                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-                if (p.residual) v += p.residual[rowoff + o + e];
-            } else {                                        // backward: (grad + residual grad) * act'(saved)
-                if (p.residual) v += p.residual[rowoff + o + e];
-                const float s = p.saved[rowoff + o + e];
-                if (p.act == ACT_RELU) v = s > 0.f ? v : 0.f;
-                else if (p.act == ACT_LRELU) v = s > 0.f ? v : 0.01f * v;
+        for (int gg = 0; gg < 4; ++gg) {
+            const int o = o0 + 32 * mi + 8 * gg + 4 * lh;
+            if (o >= p.cout) continue;
+            const bool v4 = vec && o + 3 < p.cout;
+            float v[4], bi[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f};
+            if (v4) {
+                if (p.bias) { const float4 q = ld4(p.bias + o); bi[0] = q.x; bi[1] = q.y; bi[2] = q.z; bi[3] = q.w; }
+                if (p.residual) { const float4 q = ld4(p.residual + rowoff + o); rs[0] = q.x; rs[1] = q.y; rs[2] = q.z; rs[3] = q.w; }
+                if (p.saved) { const float4 q = ld4(p.saved + rowoff + o); sv[0] = q.x; sv[1] = q.y; sv[2] = q.z; sv[3] = q.w; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (o + e >= p.cout) continue;
+                    if (p.bias) bi[e] = p.bias[o + e];
+                    if (p.residual) rs[e] = p.residual[rowoff + o + e];
+                    if (p.saved) sv[e] = p.saved[rowoff + o + e];
+                }
             }
-            p.y[rowoff + o + e] = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[j][4 * gg + e] + bi[e];
+                if (p.saved == nullptr) {                       // forward
+                    if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+                    else if (p.act == ACT_LRELU) x = x > 0.f ? x : 0.01f * x;
+                    x += rs[e];
+                } else {                                        // backward: (grad + residual grad) * act'(saved)
+                    x += rs[e];
+                    if (p.act == ACT_RELU) x = sv[e] > 0.f ? x : 0.f;
+                    else if (p.act == ACT_LRELU) x = sv[e] > 0.f ? x : 0.01f * x;
+                }
+                v[e] = x;
+            }
+            if (v4) *reinterpret_cast<float4*>(p.y + rowoff + o) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (o + e < p.cout) p.y[rowoff + o + e] = v[e];
+            }
         }
     }
 }
@@ -148,13 +195,16 @@ __global__ void repack_weights_kernel(const float* __restrict__ w, float* __rest
 struct WgradParams {
     const float* x;    // [N][L][cin]
     const float* dy;   // [N][L][cout]
-    float* dw;         // [cout][cin][K]  (torch layout), accumulated with atomics
-    float* db;         // [cout] or nullptr
-    int N, L, cin, cout, K, tiles_per_wf;
+    float* part;       // workspace: [G][K][cout_pad][cin_pad] partial weight gradients
+    float* dbpart;     // workspace: [G][cout_pad] partial bias gradients
+    int N, L, cin, cout, K, tiles_per_wf, total_tiles, cin_pad, cout_pad;
 };
 
-// One work-group: 128 rows of one waveform x (64 output channels) x (64 input channels); each wave
-// owns one 32x32 (o, c) quadrant and all K taps.  Time is the MFMA reduction axis (2 rows / MFMA).
+// Persistent work-groups: blockIdx.x = g walks the 128-row tiles g, g+G, ... of the whole batch and keeps
+// the (64 output channels) x (64 input channels) x K partial weight gradient in accumulator registers;
+// each wave owns one 32x32 (o, c) quadrant and all K taps.  Time is the MFMA reduction axis (2 rows per
+// MFMA).  One partial per work-group goes to the workspace; wgrad_reduce_kernel sums the G partials in a
+// fixed order, so gradients are bitwise reproducible (no float atomics).
 constexpr int WG_ROWS = 128;
 template <int KMAX>
 __global__ __launch_bounds__(256) void conv_wgrad_cl_kernel(const WgradParams p) {
@@ -162,56 +212,67 @@ __global__ __launch_bounds__(256) void conv_wgrad_cl_kernel(const WgradParams p)
     __shared__ __attribute__((aligned(16))) float xs[(WG_ROWS + KMAX - 1) * TROWF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mi = wave & 1, ni = wave >> 1, ln = lane & 31, lh = lane >> 5;
-    const int n = blockIdx.x / p.tiles_per_wf;
-    const int t0 = (blockIdx.x - n * p.tiles_per_wf) * WG_ROWS;
     const int o0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
     const int K = p.K, pad = K >> 1;
-    for (int i = tid; i < WG_ROWS * 16; i += 256) {
-        const int r = i >> 4, q = i & 15;
-        const int t = t0 + r, o = o0 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < p.L) {
-            const float* src = p.dy + ((size_t)n * p.L + t) * p.cout + o;
-            if (o + 3 < p.cout) v = ld4(src);
-            else {
-                if (o < p.cout) v.x = src[0];
-                if (o + 1 < p.cout) v.y = src[1];
-                if (o + 2 < p.cout) v.z = src[2];
-            }
-        }
-        *reinterpret_cast<float4*>(dys + r * TROWF + 4 * q) = v;
-    }
-    for (int i = tid; i < (WG_ROWS + K - 1) * 16; i += 256) {
-        const int r = i >> 4, q = i & 15;
-        const int t = t0 - pad + r, c = c0 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < p.L) {
-            const float* src = p.x + ((size_t)n * p.L + t) * p.cin + c;
-            if (c + 3 < p.cin) v = ld4(src);
-            else {
-                if (c < p.cin) v.x = src[0];
-                if (c + 1 < p.cin) v.y = src[1];
-                if (c + 2 < p.cin) v.z = src[2];
-            }
-        }
-        *reinterpret_cast<float4*>(xs + r * TROWF + 4 * q) = v;
-    }
-    __syncthreads();
     floatx16 acc[KMAX];
 #pragma unroll
     for (int d = 0; d < KMAX; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+    float dbs = 0.f;
     // A[i = o][k = row parity], B[k][j = c]:  D[o][c] += dY[t][o] * X[t + d - pad][c]
     const float* ap = dys + lh * TROWF + 32 * mi + ln;
     const float* bp = xs + lh * TROWF + 32 * ni + ln;
-    for (int r = 0; r < WG_ROWS; r += 2) {
-        const float a = ap[r * TROWF];
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+        const int n = tile / p.tiles_per_wf;
+        const int t0 = (tile - n * p.tiles_per_wf) * WG_ROWS;
+        __syncthreads();
+        for (int i = tid; i < WG_ROWS * 16; i += 256) {
+            const int r = i >> 4, q = i & 15;
+            const int t = t0 + r, o = o0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < p.L) {
+                const float* src = p.dy + ((size_t)n * p.L + t) * p.cout + o;
+                if (o + 3 < p.cout) v = ld4(src);
+                else {
+                    if (o < p.cout) v.x = src[0];
+                    if (o + 1 < p.cout) v.y = src[1];
+                    if (o + 2 < p.cout) v.z = src[2];
+                }
+            }
+            *reinterpret_cast<float4*>(dys + r * TROWF + 4 * q) = v;
+        }
+        for (int i = tid; i < (WG_ROWS + K - 1) * 16; i += 256) {
+            const int r = i >> 4, q = i & 15;
+            const int t = t0 - pad + r, c = c0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < p.L) {
+                const float* src = p.x + ((size_t)n * p.L + t) * p.cin + c;
+                if (c + 3 < p.cin) v = ld4(src);
+                else {
+                    if (c < p.cin) v.x = src[0];
+                    if (c + 1 < p.cin) v.y = src[1];
+                    if (c + 2 < p.cin) v.z = src[2];
+                }
+            }
+            *reinterpret_cast<float4*>(xs + r * TROWF + 4 * q) = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int r = 0; r < WG_ROWS; r += 2) {
+            const float a = ap[r * TROWF];
 #pragma unroll
-        for (int d = 0; d < KMAX; ++d)
-            if (d < K) acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(r + d) * TROWF], acc[d], 0, 0, 0);
+            for (int d = 0; d < KMAX; ++d)
+                if (d < K) acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(r + d) * TROWF], acc[d], 0, 0, 0);
+        }
+        if (blockIdx.z == 0 && tid < 64) {
+            float s = 0.f;
+            for (int r = 0; r < WG_ROWS; ++r) s += dys[r * TROWF + tid];
+            dbs += s;
+        }
     }
     // accumulator register v: row (o) = 32mi + (v&3) + 8(v>>2) + 4lh, col (c) = 32ni + ln
+    float* part = p.part + (size_t)blockIdx.x * K * p.cout_pad * p.cin_pad;
     const int c = c0 + 32 * ni + ln;
 #pragma unroll
     for (int d = 0; d < KMAX; ++d) {
@@ -219,13 +280,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_cl_kernel(const WgradParams p)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int o = o0 + 32 * mi + (v & 3) + 8 * (v >> 2) + 4 * lh;
-            if (o < p.cout && c < p.cin) atomicAdd(p.dw + ((size_t)o * p.cin + c) * K + d, acc[d][v]);
+            part[((size_t)d * p.cout_pad + o) * p.cin_pad + c] = acc[d][v];
         }
     }
-    if (p.db != nullptr && blockIdx.z == 0 && tid < 64 && o0 + tid < p.cout) {
-        float s = 0.f;
-        for (int r = 0; r < WG_ROWS; ++r) s += dys[r * TROWF + tid];
-        atomicAdd(p.db + o0 + tid, s);
+    if (blockIdx.z == 0 && tid < 64) p.dbpart[(size_t)blockIdx.x * p.cout_pad + o0 + tid] = dbs;
+}
+
+// dw[o][c][d] = sum_g part[g][d][o][c];  db[o] = sum_g dbpart[g][o]   (fixed summation order).
+// One work-group: 64 consecutive elements x 4 interleaved slices of g, combined through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
+                                                           float* __restrict__ dw, float* __restrict__ db, int G, int K,
+                                                           int cout, int cin, int cout_pad, int cin_pad) {
+    __shared__ float red[4][64];
+    const int per = K * cout_pad * cin_pad;
+    const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + e;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < per) {
+        int g = gq;
+        for (; g + 4 < G; g += 8) {
+            s0 += part[(size_t)g * per + i];
+            s1 += part[(size_t)(g + 4) * per + i];
+        }
+        if (g < G) s0 += part[(size_t)g * per + i];
+    } else if (i - per < cout_pad) {
+        for (int g = gq; g < G; g += 4) s0 += dbpart[(size_t)g * cout_pad + (i - per)];
+    }
+    red[gq][e] = s0 + s1;
+    __syncthreads();
+    if (gq != 0) return;
+    const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (i < per) {
+        const int c = i % cin_pad, o = (i / cin_pad) % cout_pad, d = i / (cin_pad * cout_pad);
+        if (o < cout && c < cin) dw[((size_t)o * cin + c) * K + d] = s;
+    } else if (db != nullptr && i - per < cout) {
+        db[i - per] = s;
     }
 }
 
@@ -260,17 +349,22 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
                                                           float* __restrict__ db, int N, int L, int rows_per_block) {
     __shared__ float red[4][64][10];
     const int tid = threadIdx.x, ch = tid & 63, part = tid >> 6;
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const int r0 = blockIdx.x * rows_per_block;                 // N*L < 2^31 is checked by the caller
+    const int total = N * L;
     float acc[10];
 #pragma unroll
     for (int d = 0; d < 10; ++d) acc[d] = 0.f;
-    for (long long r = r0 + part; r < r0 + rows_per_block && r < (long long)N * L; r += 4) {
-        const int t = (int)(r % L);
+    const int rend = min(r0 + rows_per_block, total);
+    int t = (r0 + part) % L;
+#pragma unroll 4
+    for (int r = r0 + part; r < rend; r += 4) {
         const float* xr = x + (r - t);
-        const float gv = saved[r * 64 + ch] > 0.f ? g[r * 64 + ch] : 0.f;
+        const float gv = saved[(size_t)r * 64 + ch] > 0.f ? g[(size_t)r * 64 + ch] : 0.f;
 #pragma unroll
         for (int d = 0; d < 9; ++d) { const int u = t + d - 4; acc[d] = fmaf(gv, (u >= 0 && u < L) ? xr[u] : 0.f, acc[d]); }
         acc[9] += gv;
+        t += 4;
+        if (t >= L) t -= L;
     }
 #pragma unroll
     for (int d = 0; d < 10; ++d) red[part][ch][d] = acc[d];
@@ -383,23 +477,28 @@ __global__ __launch_bounds__(256) void loss_target_kernel(const long long* __res
 }
 
 // loss[0] += sum (pred - s*target)^2 / NM + lambda * sum |pred| / NM ; dpred = 2 (pred - s*target)/NM + lambda sign(pred)/NM
-__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ pred, float* __restrict__ target,
                                                         const float* __restrict__ tmax, float amplitude, float lambda,
                                                         long long count, float* __restrict__ dpred, double* __restrict__ loss) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;
-    const float scale = amplitude / tmax[0];
+    const float tm = tmax[0];
     const double inv = 1.0 / (double)count;
     double part = 0.0;
     if (i < count) {
         const float pv = pred[i];
-        const float diff = pv - target[i] * scale;
+        const float tv = target[i] / tm * amplitude;             // main.py:230-231: /= max, then *= amplitude
+        target[i] = tv;
+        const float diff = pv - tv;
         part = ((double)diff * diff + (double)lambda * fabsf(pv)) * inv;
         const float sg = pv > 0.f ? 1.f : (pv < 0.f ? -1.f : 0.f);
         dpred[i] = (float)((2.0 * diff + (double)lambda * sg) * inv);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss, part);
+    __shared__ double wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
 }
 
 // torch.optim.AdamW step (decoupled weight decay), one flat parameter vector
@@ -438,7 +537,7 @@ extern "C" int stof_train_conv(const float* x, const float* w_tapmajor, const fl
     ConvParams p;
     p.x = x; p.w = w_tapmajor; p.bias = bias; p.residual = residual; p.saved = saved; p.y = y;
     p.N = (int)N; p.L = (int)L; p.cin = cin; p.cout = cout; p.K = K; p.act = act;
-    p.tiles_per_wf = (int)((L + 63) / 64);
+    p.tiles_per_wf = (int)((L + CT - 1) / CT);
     const int64_t gx = N * p.tiles_per_wf;
     if (gx > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(conv_cl_kernel, dim3((unsigned)gx, (unsigned)((cout + 63) / 64)), dim3(256), 0,
@@ -454,21 +553,49 @@ extern "C" int stof_train_repack(const float* w, float* out, int32_t cout, int32
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
+static int wgrad_groups(int32_t cin, int32_t cout) {
+    const int blocks = ((cout + 63) / 64) * ((cin + 63) / 64);
+    const int g = 512 / blocks;
+    return g < 1 ? 1 : g;
+}
+
+extern "C" size_t stof_train_wgrad_workspace_bytes(int32_t cin, int32_t cout, int32_t K) {
+    if (cin < 1 || cout < 1 || K < 1) return 0;
+    const size_t cin_pad = (size_t)((cin + 63) / 64) * 64, cout_pad = (size_t)((cout + 63) / 64) * 64;
+    return (size_t)wgrad_groups(cin, cout) * ((size_t)K * cout_pad * cin_pad + cout_pad) * sizeof(float);
+}
+
 extern "C" int stof_train_wgrad(const float* x, const float* dy, float* dw, float* db, int64_t N, int64_t L,
-                                int32_t cin, int32_t cout, int32_t K, void* stream) {
+                                int32_t cin, int32_t cout, int32_t K, void* workspace, size_t workspace_bytes,
+                                void* stream) {
     if (N < 0 || L < 0 || cin < 1 || cout < 1 || K < 1 || K > 7 || !(K & 1)) return STOF_ERR_BAD_ARG;
-    if (N == 0 || L == 0) return STOF_OK;
-    if (!x || !dy || !dw) return STOF_ERR_BAD_ARG;
-    WgradParams p;
-    p.x = x; p.dy = dy; p.dw = dw; p.db = db; p.N = (int)N; p.L = (int)L; p.cin = cin; p.cout = cout; p.K = K;
-    p.tiles_per_wf = (int)((L + WG_ROWS - 1) / WG_ROWS);
-    const int64_t gx = N * p.tiles_per_wf;
-    if (gx > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)gx, (unsigned)((cout + 63) / 64), (unsigned)((cin + 63) / 64));
+    if (!dw) return STOF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N == 0 || L == 0) {
+        if (hipMemsetAsync(dw, 0, (size_t)cout * cin * K * sizeof(float), s) != hipSuccess) return STOF_ERR_HIP;
+        if (db && hipMemsetAsync(db, 0, (size_t)cout * sizeof(float), s) != hipSuccess) return STOF_ERR_HIP;
+        return STOF_OK;
+    }
+    if (!x || !dy || !workspace) return STOF_ERR_BAD_ARG;
+    if (workspace_bytes < stof_train_wgrad_workspace_bytes(cin, cout, K)) return STOF_ERR_WORKSPACE;
+    WgradParams p;
+    p.x = x; p.dy = dy; p.N = (int)N; p.L = (int)L; p.cin = cin; p.cout = cout; p.K = K;
+    p.cin_pad = (cin + 63) / 64 * 64; p.cout_pad = (cout + 63) / 64 * 64;
+    p.tiles_per_wf = (int)((L + WG_ROWS - 1) / WG_ROWS);
+    const int64_t tiles = N * p.tiles_per_wf;
+    if (tiles > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    p.total_tiles = (int)tiles;
+    int G = wgrad_groups(cin, cout);
+    if (G > tiles) G = (int)tiles;
+    p.part = static_cast<float*>(workspace);
+    p.dbpart = p.part + (size_t)G * K * p.cout_pad * p.cin_pad;
+    const dim3 grid((unsigned)G, (unsigned)(p.cout_pad / 64), (unsigned)(p.cin_pad / 64));
     if (K <= 3) hipLaunchKernelGGL(conv_wgrad_cl_kernel<3>, grid, dim3(256), 0, s, p);
     else if (K <= 5) hipLaunchKernelGGL(conv_wgrad_cl_kernel<5>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(conv_wgrad_cl_kernel<7>, grid, dim3(256), 0, s, p);
+    const int total = K * p.cout_pad * p.cin_pad + p.cout_pad;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, p.part, p.dbpart, dw, db, G, K, cout, cin,
+                       p.cout_pad, p.cin_pad);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
@@ -486,7 +613,8 @@ extern "C" int stof_train_conv1_wgrad(const float* x, const float* g, const floa
     if (N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     if (N == 0 || L == 0) return STOF_OK;
     if (!x || !g || !saved || !dw || !db) return STOF_ERR_BAD_ARG;
-    const int rows_per_block = 512;
+    if (N * L > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    const int rows_per_block = 256;
     hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)((N * L + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, g, saved, dw, db, (int)N, (int)L, rows_per_block);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;

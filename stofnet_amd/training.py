@@ -87,9 +87,13 @@ class StofNetTrainer:
 
     def _wgrad(self, x, dy, name, cin, cout, K):
         n, L = x.shape[0], x.shape[1]
+        need = _lib.lib().stof_train_wgrad_workspace_bytes(cin, cout, K)
+        ws = getattr(self, '_wgrad_ws', None)
+        if ws is None or ws.numel() < need:
+            ws = self._wgrad_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         _lib.check(_lib.lib().stof_train_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(self.g[name + '.weight']),
-                                               _lib.ptr(self.g[name + '.bias']), n, L, cin, cout, K, self._st()),
-                   'stof_train_wgrad')
+                                               _lib.ptr(self.g[name + '.bias']), n, L, cin, cout, K, _lib.ptr(ws), ws.numel(),
+                                               self._st()), 'stof_train_wgrad')
 
     def _add(self, a, b):
         out = torch.empty_like(a)

@@ -103,3 +103,61 @@ def test_adamw_steps_match_torch_optim(dev):
     y = m.eval()(torch.from_numpy(x).to(dev)).cpu().numpy()
     y_ref = so.stofnet_forward({k: v.detach() for k, v in p.items()}, x, r, sgs).numpy()
     assert relerr(y, y_ref) < 1e-4
+
+
+def test_training_matches_reference_golden_f8(dev):
+    """Two reference training steps (tests/golden/make_golden_training.py: reference StofNet + coords2mask +
+    gaussian_kernel + AdamW) reproduced by the HIP trainer: loss, target, all gradients, updated weights."""
+    from conftest import golden, load_weights
+    from stofnet_amd import StofNet
+    from stofnet_amd.training import StofNetTrainer
+    g = golden('f8_training')
+    sd = load_weights('different-armadillo')
+    m = StofNet(upsample_factor=4, semi_global_scale=80)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(dev)
+    lr, wd, lam, amp, ks, sigma = g['hyper']
+    tr = StofNetTrainer(m, lr=lr, weight_decay=wd, lambda_value=lam, mask_amplitude=amp, kernel_size=int(ks), sigma=sigma)
+    frame, gt = torch.from_numpy(g['frame']).to(dev), torch.from_numpy(g['gt_true']).to(dev)
+    loss, pred = tr.forward_backward(frame, gt)
+    assert relerr(pred.cpu().numpy(), g['masks_pred']) < 1e-5
+    assert abs(float(loss) - float(g['loss0'])) < 2e-6 * float(g['loss0'])
+    for name in tr.names:
+        assert relerr(tr.g[name].cpu().numpy(), g['grad.' + name]) < 2e-4, name
+    tr.step()
+    loss1, _ = tr.train_step(frame, gt)
+    assert abs(float(loss1) - float(g['loss1'])) < 1e-4 * float(g['loss1'])
+    params = dict(m.named_parameters())
+    for key in g.files if hasattr(g, 'files') else g.keys():
+        if key.startswith('after2.'):
+            # The first AdamW steps move every weight by ~lr*g/(|g|+eps): where |g| sits at fp32 rounding level the
+            # direction itself is noise (the reference is not reproducible there across thread counts either), so
+            # the tight bound is asked of the weights whose step-1 gradient is significant, and the worst case
+            # (2 steps x lr = 1e-3) of all of them.
+            got = params[key[7:]].detach().cpu().numpy()
+            diff = np.abs(got - g[key])
+            g0 = np.abs(g['grad.' + key[7:]])
+            sig = g0 > 1e-2 * g0.max()
+            assert diff[sig].max() < 2e-5, key
+            assert diff.max() < 1e-3 and (diff > 5e-5).mean() < 1e-3, key
+    total = sum(float(p.detach().double().sum()) for p in m.parameters())
+    assert abs(total - float(g['after2_sum'])) < 0.05
+
+
+def test_loss_target_matches_reference_blur(dev):
+    """The device-built target 20*blur7(onehot)/max against the reference's masks_true_blur (f8)."""
+    from conftest import golden
+    from stofnet_amd import _lib
+    g = golden('f8_training')
+    pred = torch.from_numpy(g['masks_pred']).to(dev).reshape(4, -1).contiguous()
+    gt = torch.from_numpy(g['gt_true']).to(dev).reshape(4, -1).contiguous()
+    from stofnet_amd.training import gaussian_kernel
+    taps = torch.tensor(gaussian_kernel(7, 1.0), dtype=torch.float32, device=dev)
+    target, dpred = torch.empty_like(pred), torch.empty_like(pred)
+    tmax = torch.empty(1, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().stof_train_loss(_lib.ptr(pred), _lib.ptr(gt), gt.shape[1], _lib.ptr(taps), 4, pred.shape[1], 20.0, 1e-2,
+                                          _lib.ptr(target), _lib.ptr(tmax), _lib.ptr(dpred), _lib.ptr(loss), _lib.stream_ptr(dev)),
+               'stof_train_loss')
+    assert np.abs(target.cpu().numpy() - g['masks_true_blur'].reshape(4, -1)).max() < 2e-6 * 20
+    assert abs(float(loss[0]) - float(g['loss0'])) < 2e-6 * float(g['loss0'])

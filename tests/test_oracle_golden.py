@@ -230,3 +230,16 @@ def test_flops_model():
     assert abs(so.flops_per_waveform(2000, 10) - 1.9351e9) < 1e6
     assert abs(so.flops_per_waveform(1536, 4) - 1.4826e9) < 1e6
     assert abs(so.flops_per_waveform(2000, 4, 1) - 1.2669e9) < 1e6
+
+
+def test_f8_training_oracle_matches_reference_step():
+    """oracle/train_oracle.py (loss of main.py:228-232 + autograd) against the reference's own fwd+bwd (f8)."""
+    from oracle import train_oracle as to
+    g = golden('f8_training')
+    sd = load_weights('different-armadillo')
+    loss, grads, pred = to.loss_and_grads(sd, g['frame'], g['gt_true'], 4, 80, dtype=torch.float32)
+    assert np.abs(pred - g['masks_pred']).max() <= 1e-5 * np.abs(g['masks_pred']).max()
+    assert abs(loss - float(g['loss0'])) < 1e-6 * float(g['loss0'])
+    for k, v in grads.items():
+        ref = g['grad.' + k]
+        assert np.abs(v - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9, k

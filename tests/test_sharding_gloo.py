@@ -68,3 +68,29 @@ def test_gather_onsets_world2(th):
     scores = rng.standard_normal((7, 1, 300)).astype(np.float32)
     scores[3, 0, 40] = scores[3, 0, 200] = 9.0       # a tie -> Kmax differs between shards
     mp.spawn(_worker, args=(2, _free_port(), scores, th), nprocs=2, join=True)
+
+
+def _grad_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from stofnet_amd.training import allreduce_mean_
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    try:
+        g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        allreduce_mean_(g)
+        q.put((rank, g.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_gradient_bucket_mean_allreduce_world2():
+    """DDP semantics of the training step's single flat gradient bucket (stofnet_amd/training.py)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000 + 7
+    ps = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in ps]
+    expect = np.arange(1000, dtype=np.float32) * 1.5
+    assert np.array_equal(res[0], expect) and np.array_equal(res[1], expect)
