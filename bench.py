@@ -87,6 +87,62 @@ def cpu_baseline(sd, r, sample_rows=256, reps=3):
                       f'{reps} reps after warm-up, torch {torch.__version__}'}
 
 
+def train_bench(args, dev, dist, rank, world):
+    """BASELINE.json configs[4]: one training step = forward (activations kept) + Gaussian-mask loss + backward +
+    mean all-reduce of the single 2.58 MB gradient bucket (RCCL, N > 1) + AdamW, exact fp32, batch per GPU fixed."""
+    from oracle import synth                      # deterministic inputs/weights only
+    from stofnet_amd import StofNet
+    from stofnet_amd.training import StofNetTrainer
+    sd = synth.synth_state_dict(R, seed=3008)
+    model = StofNet(upsample_factor=R)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    tr = StofNetTrainer(model.to(dev))
+    nb = args.train_batch
+    x = torch.from_numpy(synth.synth_echo(nb, L, seed=3008 + rank)).to(dev)
+    rng = np.random.default_rng(rank)
+    gt = torch.from_numpy(np.sort(rng.integers(1, L * R, size=(nb, 1, 2)), -1)).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        loss, _ = tr.train_step(x, gt)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = tr.train_step(x, gt)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        flops = 3.0 * total_flops(nb, L, R)        # forward + data-gradient + weight-gradient
+        achieved = flops * args.steps / dt / 1e12
+        print(json.dumps({
+            'metric': 'RF waveforms/sec StofNet training step (fwd+bwd+AdamW) rf_scale=10',
+            'value': round(world * nb * args.steps / dt, 1), 'unit': 'waveforms/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'C5 training step [{nb},1,{L}] -> [{nb},1,{L * R}] per GPU, Gaussian-mask loss, AdamW, '
+                                   f'upsample_factor={R}', 'rows_per_gpu': nb, 'L': L, 'upsample_factor': R,
+                       'parallelism': f'ddp{world}: one flat 2.58 MB gradient all-reduce per step'},
+            'roofline': {'bound': 'mfma', 'kernel': 'whole step (conv_cl_kernel + conv_wgrad_cl_kernel, fp32 MFMA)',
+                         'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS['fp32'], 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_TFLOPS['fp32'], 4), 'traffic': None},
+            'final_loss': float(loss),
+        }), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -95,6 +151,9 @@ def main():
     ap.add_argument('--precision', default=os.environ.get('STOF_PRECISION', 'f16x3'), choices=['fp32', 'f16x3'])
     ap.add_argument('--no-fp32-extra', action='store_true', help='skip the secondary exact-fp32 measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
+                    help="'train' times BASELINE.json configs[4] (fwd+bwd+AdamW, DDP gradient all-reduce) instead")
+    ap.add_argument('--train-batch', type=int, default=256, help='waveforms per GPU per training step')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -110,6 +169,9 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
+
+    if args.mode == 'train':
+        return train_bench(args, dev, dist, rank, world)
 
     from oracle import synth                      # deterministic inputs/weights only (not the oracle math)
     from stofnet_amd import StofNet, _lib

@@ -5,9 +5,12 @@
 What it keeps: config.yaml + CLI merge, seeding (main.py:39-41), the model switch
 (stofnet / gradpeak, main.py:133-167), checkpoint lookup by file-name prefix with strict
 load_state_dict (main.py:173-177), the eval loop's `model(frame)` -> `mask2coords` ->
-`toa_rmse` sequence (main.py:314,320,347).  What it drops: datasets (absent from the
-reference mount), training, wandb.  Inputs come from `input_file` (.npy) or from synthetic
-echoes with known onsets.
+`toa_rmse` sequence (main.py:314,320,347), and with `evaluate=False` the training loop
+(main.py:199-289: Gaussian-mask loss, AdamW, CosineAnnealingLR per epoch, EarlyStopping on the
+summed validation loss, checkpoint `<run_name>_rf-scale<rf>_epoch_<e>.pth`, main.py:423-426) on the
+HIP training kernels; launched under torch.distributed.run it becomes DDP (batch sharded over ranks,
+one flat gradient all-reduce per step over RCCL).  What it drops: datasets (absent from the reference
+mount) and wandb.  Inputs come from `input_file` (.npy) or from synthetic echoes with known onsets.
 """
 import json
 import os
@@ -53,6 +56,9 @@ def main(argv=None):
         cfg.evaluate = True
     else:
         raise Exception('Model not recognized')
+    if 'LOCAL_RANK' in os.environ and str(cfg.device) == 'cuda':          # one process per GPU under torch.distributed.run
+        cfg.device = f"cuda:{os.environ['LOCAL_RANK']}"
+        torch.cuda.set_device(cfg.device)
     model = model.to(cfg.device)
     model.eval()
 
@@ -64,6 +70,73 @@ def main(argv=None):
             model.load_state_dict(torch.load(str(paths[0]), map_location=cfg.device, weights_only=True))
 
     frames, gt = load_frames(cfg)
+    history = train(model, frames, gt, cfg) if (not cfg.evaluate and name == 'stofnet') else None
+    es_all, summary = evaluate(model, name, frames, gt, cfg)
+    if history is not None:
+        summary['train_history'] = history
+    if int(os.environ.get('RANK', '0')) == 0:
+        print(json.dumps(summary))
+    return es_all, summary
+
+
+def train(model, frames, gt, cfg):
+    """main.py:199-289 + 403-410 + 423-426 on the HIP training kernels (stofnet_amd/training.py)."""
+    import torch.distributed as dist
+    from stofnet_amd.sharding import shard_rows
+    from stofnet_amd.training import StofNetTrainer
+    if gt is None:
+        raise RuntimeError('training needs ground-truth onsets (synthetic echoes or a labelled input)')
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group('nccl', device_id=torch.device(cfg.device))
+    tr = StofNetTrainer(model, lr=cfg.lr, weight_decay=cfg.weight_decay, lambda_value=cfg.lambda_value,
+                        mask_amplitude=cfg.mask_amplitude, kernel_size=cfg.kernel_size, sigma=cfg.sigma)
+    r, bs = int(cfg.upsample_factor), int(cfg.batch_size)
+    n_val = max(bs, int(frames.shape[0] * 0.1) // bs * bs)              # held-out tail for early stopping
+    tr_x, tr_gt = frames[:-n_val], gt[:-n_val]
+    va_x, va_gt = frames[-n_val:], gt[-n_val:]
+    lo, hi = shard_rows(tr_x.shape[0] // bs, rank, world)                # whole batches per rank
+    best, bad, history = float('inf'), 0, []
+
+    def gt_true_of(g):
+        g = torch.from_numpy(np.nan_to_num(g, nan=0.0)).to(cfg.device)
+        g = torch.where(g <= 0, torch.zeros_like(g), g)                  # main.py:217
+        return torch.round(g.unsqueeze(1) * r).long()                    # main.py:218
+
+    for e in range(int(cfg.epochs)):
+        tr.set_lr_cosine(e, int(cfg.epochs), float(cfg.lr))              # CosineAnnealingLR stepped per epoch
+        model.train()
+        tot = 0.0
+        for b in range(lo, hi):
+            sl = slice(b * bs, (b + 1) * bs)
+            loss, _ = tr.train_step(torch.from_numpy(tr_x[sl]).to(cfg.device), gt_true_of(tr_gt[sl]))
+            tot += float(loss)
+        model.eval()
+        val = 0.0
+        with torch.no_grad():
+            for b0 in range(0, va_x.shape[0] - bs + 1, bs):
+                pred = model(torch.from_numpy(va_x[b0:b0 + bs]).to(cfg.device))
+                val += float(tr.loss(pred, gt_true_of(va_gt[b0:b0 + bs])))
+        history.append({'epoch': e, 'lr': tr.lr, 'train_loss': tot / max(hi - lo, 1), 'val_loss': val})
+        if rank == 0:
+            print(json.dumps(history[-1]))
+        if val < best - float(cfg.delta):                                # EarlyStopping (utils/early_stop.py)
+            best, bad = val, 0
+        else:
+            bad += 1
+            if bad >= int(cfg.patience):
+                break
+    if rank == 0 and cfg.ckpt_dir:
+        ckpt_dir = Path(cfg.ckpt_dir) if os.path.isabs(str(cfg.ckpt_dir)) else script_path / cfg.ckpt_dir
+        ckpt_dir.mkdir(exist_ok=True)
+        path = ckpt_dir / f"{cfg.run_name}_rf-scale{cfg.rf_scale_factor}_epoch_{e + 1}.pth"
+        torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, path)
+        print(json.dumps({'saved': str(path)}))
+    return history
+
+
+def evaluate(model, name, frames, gt, cfg):
     bs = int(cfg.batch_size)
     results, times = [], []
     with torch.no_grad():
@@ -90,7 +163,6 @@ def main(argv=None):
                         tol=cfg.etol).cpu()
         summary['total_distance_mean'] = float(np.nanmean(errs[:, 0].numpy()))
         summary['total_jaccard'] = float(np.nanmean(errs[:, 3].numpy()))
-    print(json.dumps(summary))
     return es_all, summary
 
 

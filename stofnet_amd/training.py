@@ -180,6 +180,21 @@ class StofNetTrainer:
                                                   _lib.ptr(self.g['conv1.bias']), n, L, st), 'stof_train_conv1_wgrad')
         return loss[0], pred.view(n, 1, L * r)
 
+    def loss(self, masks_pred: torch.Tensor, gt_true: torch.Tensor) -> torch.Tensor:
+        """Loss value only (validation, main.py:322-327) for predictions [N,1,M]."""
+        _lib.require_device(masks_pred, 'masks_pred')
+        pred = masks_pred.detach().reshape(masks_pred.shape[0], -1).contiguous().float()
+        n, m = pred.shape
+        gt = gt_true.detach().reshape(n, -1).contiguous().to(self.dev, torch.int64)
+        target, dpred = torch.empty_like(pred), torch.empty_like(pred)
+        tmax = torch.empty(1, dtype=torch.float32, device=self.dev)
+        loss = torch.empty(1, dtype=torch.float64, device=self.dev)
+        with torch.cuda.device(self.dev):
+            _lib.check(_lib.lib().stof_train_loss(_lib.ptr(pred), _lib.ptr(gt), gt.shape[1], _lib.ptr(self.taps), n, m, self.amp,
+                                                  self.lam, _lib.ptr(target), _lib.ptr(tmax), _lib.ptr(dpred), _lib.ptr(loss),
+                                                  self._st()), 'stof_train_loss')
+        return loss[0]
+
     def allreduce_grads(self):
         """DDP semantics: average the flat gradient bucket over the process group (RCCL over xGMI on the
         GPU node; one 2.58 MB all-reduce per step, latency-bound)."""
