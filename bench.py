@@ -125,7 +125,7 @@ def train_bench(args, dev, dist, rank, world):
     if rank == 0:
         flops = 3.0 * total_flops(nb, L, R)        # forward + data-gradient + weight-gradient
         achieved = flops * args.steps / dt / 1e12
-        print(json.dumps({
+        out = {
             'metric': 'RF waveforms/sec StofNet training step (fwd+bwd+AdamW) rf_scale=10',
             'value': round(world * nb * args.steps / dt, 1), 'unit': 'waveforms/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
@@ -137,7 +137,21 @@ def train_bench(args, dev, dist, rank, world):
                          'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS['fp32'], 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_TFLOPS['fp32'], 4), 'traffic': None},
             'final_loss': float(loss),
-        }), flush=True)
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # the oracle's training step (torch autograd on the host cores), bounded sample
+            from oracle import train_oracle
+            cores = host_cores()
+            torch.set_num_threads(cores)
+            rows = 32
+            xs, gts = x[:rows].cpu().numpy(), gt[:rows].cpu().numpy()
+            train_oracle.loss_and_grads(sd, xs[:4], gts[:4], R, 80, dtype=torch.float32)
+            t1 = time.perf_counter()
+            train_oracle.loss_and_grads(sd, xs, gts, R, 80, dtype=torch.float32)
+            cdt = time.perf_counter() - t1
+            out['cpu_baseline'] = {'value': round(rows / cdt, 2), 'unit': 'waveforms/s', 'cores': cores, 'kind': 'port',
+                                   'sample': f'1 fwd+bwd of {rows} waveforms (oracle, torch autograd fp32), optimizer step excluded'}
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
