@@ -96,7 +96,7 @@ def train_bench(args, dev, dist, rank, world):
     sd = synth.synth_state_dict(R, seed=3008)
     model = StofNet(upsample_factor=R)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
-    tr = StofNetTrainer(model.to(dev))
+    tr = StofNetTrainer(model.to(dev), precision=args.train_precision)
     nb = args.train_batch
     x = torch.from_numpy(synth.synth_echo(nb, L, seed=3008 + rank)).to(dev)
     rng = np.random.default_rng(rank)
@@ -129,7 +129,9 @@ def train_bench(args, dev, dist, rank, world):
             'metric': 'RF waveforms/sec StofNet training step (fwd+bwd+AdamW) rf_scale=10',
             'value': round(world * nb * args.steps / dt, 1), 'unit': 'waveforms/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.train_precision == 'fp32' else 'f32 (fwd/dgrad convs via split-fp16 x3 MFMA operands; wgrad exact f32)',
+            'data': 'synthetic',
             'config': {'workload': f'C5 training step [{nb},1,{L}] -> [{nb},1,{L * R}] per GPU, Gaussian-mask loss, AdamW, '
                                    f'upsample_factor={R}', 'rows_per_gpu': nb, 'L': L, 'upsample_factor': R,
                        'parallelism': f'ddp{world}: one flat 2.58 MB gradient all-reduce per step'},
@@ -168,6 +170,8 @@ def main():
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="'train' times BASELINE.json configs[4] (fwd+bwd+AdamW, DDP gradient all-reduce) instead")
     ap.add_argument('--train-batch', type=int, default=256, help='waveforms per GPU per training step')
+    ap.add_argument('--train-precision', default='fp32', choices=['fp32', 'f16x3'],
+                    help='arithmetic of the forward / data-gradient convolutions of the training step')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))

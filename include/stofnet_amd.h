@@ -182,25 +182,29 @@ int stof_toa_rmse(const float* gt, const float* es, int64_t N, int64_t G, int64_
 #define STOF_ACT_LRELU 2
 
 /* Conv1d weights (cout, cin, K) -> tap-major [K][cout][cin] (transpose_flip = 0, forward) or the
- * data-gradient operand [K][cin][cout] with flipped taps (transpose_flip = 1).                      */
-int stof_train_repack(const float* w, float* out, int32_t cout, int32_t cin, int32_t K,
-                      int32_t transpose_flip, void* stream);
+ * data-gradient operand [K][cin][cout] with flipped taps (transpose_flip = 1).  precision = STOF_PREC_F16X3
+ * writes the split-fp16 operand image instead ([K][A][B_pad/64][64 hi | 64 lo]); `out` must hold
+ * stof_train_repack_floats() floats.  stof_train_conv must be called with the same precision.       */
+size_t stof_train_repack_floats(int32_t cout, int32_t cin, int32_t K, int32_t transpose_flip, int32_t precision);
+int stof_train_repack(const float* w, float* out, int32_t cout, int32_t cin, int32_t K, int32_t transpose_flip,
+                      int32_t precision, void* stream);
 /* y = act(bias + conv_same(x, w)) + residual                     (saved == NULL: F.conv1d forward,
  *                                                                   models/stofnet.py:45,56,62,65,100,106)
  * y = (conv_same(x, w) + residual) * act'(saved)                  (saved != NULL: autograd of the same ops)
  * x[N,L,cin], w tap-major [K][cout][cin], y/residual/saved [N,L,cout]; K odd <= 9.                  */
 int stof_train_conv(const float* x, const float* w_tapmajor, const float* bias, const float* residual,
                     const float* saved, float* y, int64_t N, int64_t L, int32_t cin, int32_t cout,
-                    int32_t K, int32_t act, void* stream);
+                    int32_t K, int32_t act, int32_t precision, void* stream);
 /* dw (cout,cin,K) = sum_t dy[t][o] x[t+d-pad][c];  db[cout] = sum_t dy[t][o]  (db may be NULL).  Overwrites
  * dw/db; partial sums go through `workspace` and are added in a fixed order (bitwise reproducible).   */
 size_t stof_train_wgrad_workspace_bytes(int32_t cin, int32_t cout, int32_t K);
 int stof_train_wgrad(const float* x, const float* dy, float* dw, float* db, int64_t N, int64_t L,
-                     int32_t cin, int32_t cout, int32_t K, void* workspace, size_t workspace_bytes, void* stream);
+                     int32_t cin, int32_t cout, int32_t K, float out_scale, void* workspace, size_t workspace_bytes,
+                     void* stream);
 /* conv1 (1->64, k9) + ReLU forward to channel-last, and its weight gradient (g masked by relu').    */
 int stof_train_conv1(const float* x, const float* w, const float* b, float* y, int64_t N, int64_t L, void* stream);
 int stof_train_conv1_wgrad(const float* x, const float* g, const float* saved, float* dw, float* db,
-                           int64_t N, int64_t L, void* stream);
+                           int64_t N, int64_t L, float out_scale, void* stream);
 /* SemiGlobalBlock pieces (models/stofnet.py:103,108-115): MaxPool1d(80) with arg-max, its routing
  * backward (times lrelu' of the pre-pool activation), nearest upsample + pad + add and its backward. */
 int stof_train_pool(const float* c, float* pooled, uint8_t* arg, int64_t N, int64_t L, int64_t P, int32_t C, void* stream);
@@ -211,9 +215,12 @@ int stof_train_upsample_add(const float* a, const float* e, float* out, int64_t 
 int stof_train_upsample_bwd(const float* g, const float* e, float* ge, int64_t N, int64_t L, int64_t P,
                             int32_t rem_half, void* stream);
 /* Loss of main.py:228-232: target = amplitude * blur7(coords2mask(gt)) / max, loss = MSE + lambda * mean|pred|;
- * writes target[N*M], tmax[1], dpred[N*M] = dloss/dpred and loss[1] (double).                        */
+ * writes target[N*M], tmax[1], dpred[N*M] = grad_scale * dloss/dpred and loss[1] (double).  grad_scale is a power
+ * of two (loss scaling: keeps the back-propagated values inside the fp16 range of the f16x3 mode); the weight-
+ * gradient entry points undo it with out_scale = 1/grad_scale, both exactly.                           */
 int stof_train_loss(const float* pred, const int64_t* gt_idx, int64_t G, const float* taps7, int64_t N, int64_t M,
-                    float amplitude, float lambda, float* target, float* tmax, float* dpred, double* loss, void* stream);
+                    float amplitude, float lambda, float grad_scale, float* target, float* tmax, float* dpred,
+                    double* loss, void* stream);
 /* out = a + b (gradient joins of the residual / long-skip branches, models/stofnet.py:56,62).         */
 int stof_train_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* torch.optim.AdamW step on one flat parameter vector (main.py:179,248).                             */

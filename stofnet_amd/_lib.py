@@ -69,17 +69,18 @@ _SIGNATURES = {
                               _c.c_int32, _c.c_void_p]),
     'stof_toa_rmse': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float,
                                  _c.c_void_p, _c.c_void_p]),
-    'stof_train_repack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_void_p]),
-    'stof_train_conv': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_void_p]),
+    'stof_train_repack_floats': (_c.c_size_t, [_c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32]),
+    'stof_train_repack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_void_p]),
+    'stof_train_conv': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_void_p]),
     'stof_train_wgrad_workspace_bytes': (_c.c_size_t, [_c.c_int32, _c.c_int32, _c.c_int32]),
-    'stof_train_wgrad': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    'stof_train_wgrad': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_float, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     'stof_train_conv1': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
-    'stof_train_conv1_wgrad': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
+    'stof_train_conv1_wgrad': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_void_p]),
     'stof_train_pool': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p]),
     'stof_train_pool_bwd': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p]),
     'stof_train_upsample_add': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p]),
     'stof_train_upsample_bwd': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p]),
-    'stof_train_loss': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_float, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'stof_train_loss': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'stof_train_add': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
     'stof_train_adamw': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_int64, _c.c_void_p]),
 }

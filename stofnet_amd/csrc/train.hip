@@ -18,6 +18,9 @@
 using namespace stof;
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -32,6 +35,27 @@ __device__ __forceinline__ floatx16 mma8(float4 a, float4 b, floatx16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
     return c;
+}
+
+// x = hi + lo in fp16 (22 significant bits): D += Ah*Bh + Ah*Bl + Al*Bh over 16 channels, fp32 accumulate
+__device__ __forceinline__ floatx16 mma16x3(uint4 ah, uint4 al, uint4 bh, uint4 bl, floatx16 c) {
+    union U { uint4 u; half8 h; };
+    U a, b, cl, d;
+    a.u = ah; b.u = bh; cl.u = al; d.u = bl;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, d.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl.h, b.h, c, 0, 0, 0);
+    return c;
+}
+// 4 fp32 values -> (hi, lo) fp16 quads packed as two 8-byte words
+__device__ __forceinline__ void split4(float4 v, uint2& hi, uint2& lo) {
+    const float4v f = {v.x, v.y, v.z, v.w};
+    const half4v h = __builtin_convertvector(f, half4v);
+    const float4v d = f - __builtin_convertvector(h, float4v);
+    const half4v l = __builtin_convertvector(d, half4v);
+    union { half4v h; uint2 u; } a, b;
+    a.h = h; b.h = l;
+    hi = a.u; lo = b.u;
 }
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
@@ -51,6 +75,7 @@ struct ConvParams {
 // the weight fragments.  The weight tile of the next (block, tap) step is fetched from L2 into registers
 // while the MFMAs of the current one run, and lands in the other half of a double-buffered LDS tile.
 constexpr int CT = 128;
+template <int PREC>
 __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(16))) float xs[(CT + 8) * TROWF];
     __shared__ __attribute__((aligned(16))) float ws[2][64 * TROWF];
@@ -74,15 +99,21 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u, o = i >> 4, q = i & 15;
-            const int c = c0 + 4 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (o0 + o < p.cout) {
-                const float* src = p.w + ((size_t)d * p.cout + o0 + o) * p.cin + c;
-                if (c + 3 < p.cin) v = ld4(src);
-                else {
-                    if (c < p.cin) v.x = src[0];
-                    if (c + 1 < p.cin) v.y = src[1];
-                    if (c + 2 < p.cin) v.z = src[2];
+            if constexpr (PREC == STOF_PREC_F16X3) {
+                // split layout [K][cout][cin_pad/64][64 hi | 64 lo halfs]: a 256-byte row per (tap, o, block) -- pure copy
+                if (o0 + o < p.cout)
+                    v = ld4(p.w + (((size_t)d * p.cout + o0 + o) * ((p.cin + 63) >> 6) + (c0 >> 6)) * 64 + 4 * q);
+            } else {
+                const int c = c0 + 4 * q;
+                if (o0 + o < p.cout) {
+                    const float* src = p.w + ((size_t)d * p.cout + o0 + o) * p.cin + c;
+                    if (c + 3 < p.cin) v = ld4(src);
+                    else {
+                        if (c < p.cin) v.x = src[0];
+                        if (c + 1 < p.cin) v.y = src[1];
+                        if (c + 2 < p.cin) v.z = src[2];
+                    }
                 }
             }
             wreg[u] = v;
@@ -108,7 +139,15 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
                         if (c + 2 < p.cin) v.z = src[2];
                     }
                 }
-                *reinterpret_cast<float4*>(xs + r * TROWF + 4 * q) = v;
+                if constexpr (PREC == STOF_PREC_F16X3) {
+                    uint2 hi, lo;
+                    split4(v, hi, lo);
+                    char* row = reinterpret_cast<char*>(xs + r * TROWF);
+                    *reinterpret_cast<uint2*>(row + 8 * q) = hi;
+                    *reinterpret_cast<uint2*>(row + 128 + 8 * q) = lo;
+                } else {
+                    *reinterpret_cast<float4*>(xs + r * TROWF + 4 * q) = v;
+                }
             }
         }
         float* wb = ws[s & 1];
@@ -121,11 +160,24 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
         if (s + 1 < nsteps) wfetch(s + 1);
         const float* arow = wb + (32 * mi + ln) * TROWF + 4 * lh;
         const float* brow = xs + (64 * ni + ln + d) * TROWF + 4 * lh;
+        if constexpr (PREC == STOF_PREC_F16X3) {
+            const char* ar = reinterpret_cast<const char*>(wb + (32 * mi + ln) * TROWF) + 16 * lh;
+            const char* br = reinterpret_cast<const char*>(xs + (64 * ni + ln + d) * TROWF) + 16 * lh;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 a = ld4(arow + 8 * q);
-            acc[0] = mma8(a, ld4(brow + 8 * q), acc[0]);
-            acc[1] = mma8(a, ld4(brow + 32 * TROWF + 8 * q), acc[1]);
+            for (int q = 0; q < 4; ++q) {
+                const uint4 ah = *reinterpret_cast<const uint4*>(ar + 32 * q), al = *reinterpret_cast<const uint4*>(ar + 128 + 32 * q);
+                acc[0] = mma16x3(ah, al, *reinterpret_cast<const uint4*>(br + 32 * q),
+                                 *reinterpret_cast<const uint4*>(br + 128 + 32 * q), acc[0]);
+                acc[1] = mma16x3(ah, al, *reinterpret_cast<const uint4*>(br + 32 * TROWF * 4 + 32 * q),
+                                 *reinterpret_cast<const uint4*>(br + 32 * TROWF * 4 + 128 + 32 * q), acc[1]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 a = ld4(arow + 8 * q);
+                acc[0] = mma8(a, ld4(brow + 8 * q), acc[0]);
+                acc[1] = mma8(a, ld4(brow + 32 * TROWF + 8 * q), acc[1]);
+            }
         }
     }
     // epilogue: lane (ln, lh) holds time row t0 + 64ni + 32j + ln, channels o0 + 32mi + 8gg + 4lh + e
@@ -190,6 +242,23 @@ __global__ void repack_weights_kernel(const float* __restrict__ w, float* __rest
         const int o = i % cout, c = (i / cout) % cin, d = i / (cin * cout);      // out[d][c][o]
         out[i] = w[((size_t)o * cin + c) * K + (K - 1 - d)];
     }
+}
+
+// Same, as the operand image of the f16x3 mode: [K][A][B_pad/64][64 hi | 64 lo] fp16 (B padded with zeros to 64)
+__global__ void repack_weights_split_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int cout, int cin, int K,
+                                            int transpose_flip) {
+    const int A = transpose_flip ? cin : cout, B = transpose_flip ? cout : cin;
+    const int Bp = (B + 63) & ~63;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * A * Bp) return;
+    const int b = i % Bp, a = (i / Bp) % A, d = i / (Bp * A);
+    float v = 0.f;
+    if (b < B) v = transpose_flip ? w[((size_t)b * cin + a) * K + (K - 1 - d)] : w[((size_t)a * cin + b) * K + d];
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    const size_t row = ((size_t)d * A + a) * (Bp >> 6) + (b >> 6);
+    out[row * 128 + (b & 63)] = h;
+    out[row * 128 + 64 + (b & 63)] = l;
 }
 
 struct WgradParams {
@@ -290,7 +359,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_cl_kernel(const WgradParams p)
 // One work-group: 64 consecutive elements x 4 interleaved slices of g, combined through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                            float* __restrict__ dw, float* __restrict__ db, int G, int K,
-                                                           int cout, int cin, int cout_pad, int cin_pad) {
+                                                           int cout, int cin, int cout_pad, int cin_pad, float out_scale) {
     __shared__ float red[4][64];
     const int per = K * cout_pad * cin_pad;
     const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
@@ -309,7 +378,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     red[gq][e] = s0 + s1;
     __syncthreads();
     if (gq != 0) return;
-    const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    const float s = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * out_scale;
     if (i < per) {
         const int c = i % cin_pad, o = (i / cin_pad) % cout_pad, d = i / (cin_pad * cout_pad);
         if (o < cout && c < cin) dw[((size_t)o * cin + c) * K + d] = s;
@@ -346,7 +415,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 // dW1[ch][d] += sum_t g'[t][ch] x[t+d-4], db1[ch] += sum_t g'[t][ch], g' = g * relu'(saved conv1 output)
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                           const float* __restrict__ saved, float* __restrict__ dw,
-                                                          float* __restrict__ db, int N, int L, int rows_per_block) {
+                                                          float* __restrict__ db, int N, int L, int rows_per_block,
+                                                          float out_scale) {
     __shared__ float red[4][64][10];
     const int tid = threadIdx.x, ch = tid & 63, part = tid >> 6;
     const int r0 = blockIdx.x * rows_per_block;                 // N*L < 2^31 is checked by the caller
@@ -372,7 +442,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     if (part == 0) {
 #pragma unroll
         for (int d = 0; d < 10; ++d) {
-            const float s = (red[0][ch][d] + red[1][ch][d]) + (red[2][ch][d] + red[3][ch][d]);
+            const float s = ((red[0][ch][d] + red[1][ch][d]) + (red[2][ch][d] + red[3][ch][d])) * out_scale;
             if (d < 9) atomicAdd(dw + ch * 9 + d, s); else atomicAdd(db + ch, s);
         }
     }
@@ -479,7 +549,8 @@ __global__ __launch_bounds__(256) void loss_target_kernel(const long long* __res
 // loss[0] += sum (pred - s*target)^2 / NM + lambda * sum |pred| / NM ; dpred = 2 (pred - s*target)/NM + lambda sign(pred)/NM
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ pred, float* __restrict__ target,
                                                         const float* __restrict__ tmax, float amplitude, float lambda,
-                                                        long long count, float* __restrict__ dpred, double* __restrict__ loss) {
+                                                        long long count, float grad_scale, float* __restrict__ dpred,
+                                                        double* __restrict__ loss) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     const float tm = tmax[0];
     const double inv = 1.0 / (double)count;
@@ -491,7 +562,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
         const float diff = pv - tv;
         part = ((double)diff * diff + (double)lambda * fabsf(pv)) * inv;
         const float sg = pv > 0.f ? 1.f : (pv < 0.f ? -1.f : 0.f);
-        dpred[i] = (float)((2.0 * diff + (double)lambda * sg) * inv);
+        dpred[i] = (float)((2.0 * diff + (double)lambda * sg) * inv) * grad_scale;   // power-of-two scale: exact
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
@@ -530,8 +601,9 @@ inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 
 extern "C" int stof_train_conv(const float* x, const float* w_tapmajor, const float* bias, const float* residual,
                                const float* saved, float* y, int64_t N, int64_t L, int32_t cin, int32_t cout,
-                               int32_t K, int32_t act, void* stream) {
+                               int32_t K, int32_t act, int32_t precision, void* stream) {
     if (N < 0 || L < 0 || cin < 1 || cout < 1 || K < 1 || K > 9 || !(K & 1)) return STOF_ERR_BAD_ARG;
+    if (precision != STOF_PREC_FP32 && precision != STOF_PREC_F16X3) return STOF_ERR_BAD_ARG;
     if (N == 0 || L == 0) return STOF_OK;
     if (!x || !w_tapmajor || !y) return STOF_ERR_BAD_ARG;
     ConvParams p;
@@ -540,16 +612,34 @@ extern "C" int stof_train_conv(const float* x, const float* w_tapmajor, const fl
     p.tiles_per_wf = (int)((L + CT - 1) / CT);
     const int64_t gx = N * p.tiles_per_wf;
     if (gx > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(conv_cl_kernel, dim3((unsigned)gx, (unsigned)((cout + 63) / 64)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), p);
+    const dim3 grid((unsigned)gx, (unsigned)((cout + 63) / 64));
+    if (precision == STOF_PREC_F16X3)
+        hipLaunchKernelGGL(conv_cl_kernel<STOF_PREC_F16X3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else
+        hipLaunchKernelGGL(conv_cl_kernel<STOF_PREC_FP32>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
+extern "C" size_t stof_train_repack_floats(int32_t cout, int32_t cin, int32_t K, int32_t transpose_flip, int32_t precision) {
+    if (cout < 1 || cin < 1 || K < 1) return 0;
+    if (precision != STOF_PREC_F16X3) return (size_t)cout * cin * K;
+    const size_t A = transpose_flip ? cin : cout, B = transpose_flip ? cout : cin;
+    return (size_t)K * A * ((B + 63) / 64 * 64);          // hi + lo halves = one float per (padded) element
+}
+
 extern "C" int stof_train_repack(const float* w, float* out, int32_t cout, int32_t cin, int32_t K, int32_t transpose_flip,
-                                 void* stream) {
+                                 int32_t precision, void* stream) {
     if (!w || !out || cout < 1 || cin < 1 || K < 1) return STOF_ERR_BAD_ARG;
-    hipLaunchKernelGGL(repack_weights_kernel, dim3(blocks_for((long long)cout * cin * K)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), w, out, cout, cin, K, transpose_flip);
+    if (precision == STOF_PREC_F16X3) {
+        const long long total = (long long)stof_train_repack_floats(cout, cin, K, transpose_flip, precision);
+        hipLaunchKernelGGL(repack_weights_split_kernel, dim3(blocks_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           w, reinterpret_cast<_Float16*>(out), cout, cin, K, transpose_flip);
+    } else if (precision == STOF_PREC_FP32) {
+        hipLaunchKernelGGL(repack_weights_kernel, dim3(blocks_for((long long)cout * cin * K)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), w, out, cout, cin, K, transpose_flip);
+    } else {
+        return STOF_ERR_BAD_ARG;
+    }
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
@@ -566,8 +656,8 @@ extern "C" size_t stof_train_wgrad_workspace_bytes(int32_t cin, int32_t cout, in
 }
 
 extern "C" int stof_train_wgrad(const float* x, const float* dy, float* dw, float* db, int64_t N, int64_t L,
-                                int32_t cin, int32_t cout, int32_t K, void* workspace, size_t workspace_bytes,
-                                void* stream) {
+                                int32_t cin, int32_t cout, int32_t K, float out_scale, void* workspace,
+                                size_t workspace_bytes, void* stream) {
     if (N < 0 || L < 0 || cin < 1 || cout < 1 || K < 1 || K > 7 || !(K & 1)) return STOF_ERR_BAD_ARG;
     if (!dw) return STOF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -595,7 +685,7 @@ extern "C" int stof_train_wgrad(const float* x, const float* dy, float* dw, floa
     else hipLaunchKernelGGL(conv_wgrad_cl_kernel<7>, grid, dim3(256), 0, s, p);
     const int total = K * p.cout_pad * p.cin_pad + p.cout_pad;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, p.part, p.dbpart, dw, db, G, K, cout, cin,
-                       p.cout_pad, p.cin_pad);
+                       p.cout_pad, p.cin_pad, out_scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
@@ -609,14 +699,14 @@ extern "C" int stof_train_conv1(const float* x, const float* w, const float* b, 
 }
 
 extern "C" int stof_train_conv1_wgrad(const float* x, const float* g, const float* saved, float* dw, float* db, int64_t N,
-                                      int64_t L, void* stream) {
+                                      int64_t L, float out_scale, void* stream) {
     if (N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     if (N == 0 || L == 0) return STOF_OK;
     if (!x || !g || !saved || !dw || !db) return STOF_ERR_BAD_ARG;
     if (N * L > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
     const int rows_per_block = 256;
     hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)((N * L + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, g, saved, dw, db, (int)N, (int)L, rows_per_block);
+                       static_cast<hipStream_t>(stream), x, g, saved, dw, db, (int)N, (int)L, rows_per_block, out_scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
@@ -665,8 +755,8 @@ extern "C" int stof_train_upsample_bwd(const float* g, const float* e, float* ge
 
 // scratch: tmax[1] float (zeroed here), target[N*M]; loss[1] double (zeroed here)
 extern "C" int stof_train_loss(const float* pred, const int64_t* gt_idx, int64_t G, const float* taps7, int64_t N, int64_t M,
-                               float amplitude, float lambda, float* target, float* tmax, float* dpred, double* loss,
-                               void* stream) {
+                               float amplitude, float lambda, float grad_scale, float* target, float* tmax, float* dpred,
+                               double* loss, void* stream) {
     if (N < 0 || M < 0 || G < 0) return STOF_ERR_BAD_ARG;
     if (N * M == 0) return STOF_OK;
     if (!pred || !gt_idx || !taps7 || !target || !tmax || !dpred || !loss) return STOF_ERR_BAD_ARG;
@@ -683,7 +773,7 @@ extern "C" int stof_train_loss(const float* pred, const int64_t* gt_idx, int64_t
     hipLaunchKernelGGL(loss_target_kernel, dim3((unsigned)N), dim3(256), (size_t)M * sizeof(float), s,
                        reinterpret_cast<const long long*>(gt_idx), (int)G, taps7, target, (int)N, (int)M, tmax);
     hipLaunchKernelGGL(loss_grad_kernel, dim3(blocks_for(N * M)), dim3(256), 0, s, pred, target, tmax, amplitude, lambda,
-                       (long long)(N * M), dpred, loss);
+                       (long long)(N * M), grad_scale, dpred, loss);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

@@ -33,16 +33,20 @@ class StofNetTrainer:
     buffer so the optimizer kernel and the gradient all-reduce touch a single tensor."""
 
     def __init__(self, model: StofNet, lr=5e-4, weight_decay=1e-8, lambda_value=1e-2, mask_amplitude=20,
-                 kernel_size=7, sigma=1, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+                 kernel_size=7, sigma=1, betas=(0.9, 0.999), eps=1e-8, process_group=None, precision='fp32'):
         if not model._supported():
             raise NotImplementedError('only the shipped StofNet architecture is supported')
         if kernel_size != 7:
             raise NotImplementedError('the loss kernel implements the 7-tap blur of config.yaml:23')
+        if precision not in ('fp32', 'f16x3'):
+            raise ValueError("precision must be 'fp32' or 'f16x3'")
+        self.prec = 1 if precision == 'f16x3' else 0       # convolutions fwd + data gradient; weight gradients stay exact fp32
         self.model = model
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
         self.lam, self.amp = float(lambda_value), float(mask_amplitude)
         self.group = process_group
         self.step_count = 0
+        self._gscale = 1.0
         params = list(model.named_parameters())
         dev = params[0][1].device
         _lib.require_device(params[0][1], 'model parameters')
@@ -74,14 +78,15 @@ class StofNetTrainer:
         n, L = x.shape[0], x.shape[1]
         y = torch.empty((n, L, cout), dtype=torch.float32, device=self.dev)
         _lib.check(_lib.lib().stof_train_conv(_lib.ptr(x), _lib.ptr(w_tm), _lib.ptr(bias), _lib.ptr(residual),
-                                              _lib.ptr(saved), _lib.ptr(y), n, L, cin, cout, K, act, self._st()),
+                                              _lib.ptr(saved), _lib.ptr(y), n, L, cin, cout, K, act, self.prec, self._st()),
                    'stof_train_conv')
         return y
 
     def _repack(self, w, flip):
         cout, cin, K = w.shape
-        out = torch.empty(w.numel(), dtype=torch.float32, device=self.dev)
-        _lib.check(_lib.lib().stof_train_repack(_lib.ptr(w), _lib.ptr(out), cout, cin, K, 1 if flip else 0, self._st()),
+        lib = _lib.lib()
+        out = torch.empty(lib.stof_train_repack_floats(cout, cin, K, 1 if flip else 0, self.prec), dtype=torch.float32, device=self.dev)
+        _lib.check(lib.stof_train_repack(_lib.ptr(w), _lib.ptr(out), cout, cin, K, 1 if flip else 0, self.prec, self._st()),
                    'stof_train_repack')
         return out
 
@@ -92,7 +97,8 @@ class StofNetTrainer:
         if ws is None or ws.numel() < need:
             ws = self._wgrad_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         _lib.check(_lib.lib().stof_train_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(self.g[name + '.weight']),
-                                               _lib.ptr(self.g[name + '.bias']), n, L, cin, cout, K, _lib.ptr(ws), ws.numel(),
+                                               _lib.ptr(self.g[name + '.bias']), n, L, cin, cout, K, 1.0 / self._gscale, _lib.ptr(ws),
+                                               ws.numel(),
                                                self._st()), 'stof_train_wgrad')
 
     def _add(self, a, b):
@@ -147,9 +153,12 @@ class StofNetTrainer:
             dpred = torch.empty_like(pred)
             tmax = torch.empty(1, dtype=torch.float32, device=self.dev)
             loss = torch.empty(1, dtype=torch.float64, device=self.dev)
+            # loss scaling by a power of two (exact): dloss/dpred ~ 2*diff/(N*M) would sit in the fp16 subnormal range of
+            # the f16x3 data-gradient convolutions; the weight-gradient kernels undo it with 1/scale
+            self._gscale = 2.0 ** math.floor(math.log2(max(n * L * r / 8.0, 1.0)))
             _lib.check(lib.stof_train_loss(_lib.ptr(pred), _lib.ptr(gt), gt.shape[1], _lib.ptr(self.taps), n, L * r, self.amp,
-                                           self.lam, _lib.ptr(target), _lib.ptr(tmax), _lib.ptr(dpred), _lib.ptr(loss), st),
-                       'stof_train_loss')
+                                           self.lam, self._gscale, _lib.ptr(target), _lib.ptr(tmax), _lib.ptr(dpred),
+                                           _lib.ptr(loss), st), 'stof_train_loss')
             # ---------------- backward
             dz = dpred.view(n, L, r)
             self._wgrad(x6, dz, 'conv_last', 64, r, 3)
@@ -177,7 +186,8 @@ class StofNetTrainer:
             else:
                 g_a1 = g_x0
             _lib.check(lib.stof_train_conv1_wgrad(_lib.ptr(x), _lib.ptr(g_a1), _lib.ptr(a1), _lib.ptr(self.g['conv1.weight']),
-                                                  _lib.ptr(self.g['conv1.bias']), n, L, st), 'stof_train_conv1_wgrad')
+                                                  _lib.ptr(self.g['conv1.bias']), n, L, 1.0 / self._gscale, st),
+                       'stof_train_conv1_wgrad')
         return loss[0], pred.view(n, 1, L * r)
 
     def loss(self, masks_pred: torch.Tensor, gt_true: torch.Tensor) -> torch.Tensor:
@@ -191,8 +201,8 @@ class StofNetTrainer:
         loss = torch.empty(1, dtype=torch.float64, device=self.dev)
         with torch.cuda.device(self.dev):
             _lib.check(_lib.lib().stof_train_loss(_lib.ptr(pred), _lib.ptr(gt), gt.shape[1], _lib.ptr(self.taps), n, m, self.amp,
-                                                  self.lam, _lib.ptr(target), _lib.ptr(tmax), _lib.ptr(dpred), _lib.ptr(loss),
-                                                  self._st()), 'stof_train_loss')
+                                                  self.lam, 1.0, _lib.ptr(target), _lib.ptr(tmax), _lib.ptr(dpred),
+                                                  _lib.ptr(loss), self._st()), 'stof_train_loss')
         return loss[0]
 
     def allreduce_grads(self):

@@ -15,22 +15,24 @@ def dev():
     return torch.device('cuda:0')
 
 
-def make(dev, r, sgs, seed=3):
+def make(dev, r, sgs, seed=3, precision='fp32'):
     from stofnet_amd import StofNet
     from stofnet_amd.training import StofNetTrainer
     sd = synth.synth_state_dict(r, seed=seed, semi_global_scale=sgs)
     m = StofNet(upsample_factor=r, semi_global_scale=sgs)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     m = m.to(dev)
-    return sd, m, StofNetTrainer(m, lr=5e-4, weight_decay=1e-8)
+    return sd, m, StofNetTrainer(m, lr=5e-4, weight_decay=1e-8, precision=precision)
 
 
 def relerr(a, b):
     return np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-30)
 
 
-def test_conv_kernels_vs_torch(dev):
-    """generic channel-last conv forward / dgrad / wgrad against F.conv1d and autograd (float64 truth)."""
+@pytest.mark.parametrize('prec', [0, 1])
+def test_conv_kernels_vs_torch(dev, prec):
+    """generic channel-last conv forward / dgrad / wgrad against F.conv1d and autograd (float64 truth), in the exact
+    fp32 mode and the split-fp16 (f16x3) mode of the forward / data-gradient convolutions."""
     import torch.nn.functional as F
     from stofnet_amd import _lib
     from stofnet_amd.training import StofNetTrainer
@@ -46,6 +48,8 @@ def test_conv_kernels_vs_torch(dev):
         gx, gw, gb = torch.autograd.grad(pre, [x, w, b], gy)
         t = StofNetTrainer.__new__(StofNetTrainer)
         t.dev = dev
+        t.prec = prec
+        t._gscale = 1.0
         xc = x.detach().permute(0, 2, 1).contiguous().float().to(dev)
         wd = w.detach().float().to(dev)
         y_gpu = t._conv(xc, t._repack(wd, False), b.detach().float().to(dev), cin, cout, K, 2)
@@ -59,9 +63,10 @@ def test_conv_kernels_vs_torch(dev):
         assert relerr(t.g['w.bias'].cpu().numpy(), gb.numpy()) < 2e-6
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
 @pytest.mark.parametrize('r,sgs,L', [(4, 80, 400), (10, 80, 336), (4, 1, 250)])
-def test_loss_and_all_gradients_vs_autograd(dev, r, sgs, L):
-    sd, m, tr = make(dev, r, sgs)
+def test_loss_and_all_gradients_vs_autograd(dev, r, sgs, L, precision):
+    sd, m, tr = make(dev, r, sgs, precision=precision)
     n = 3
     x = synth.synth_echo(n, L, seed=11)
     rng = np.random.default_rng(5)
@@ -105,7 +110,8 @@ def test_adamw_steps_match_torch_optim(dev):
     assert relerr(y, y_ref) < 1e-4
 
 
-def test_training_matches_reference_golden_f8(dev):
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_training_matches_reference_golden_f8(dev, precision):
     """Two reference training steps (tests/golden/make_golden_training.py: reference StofNet + coords2mask +
     gaussian_kernel + AdamW) reproduced by the HIP trainer: loss, target, all gradients, updated weights."""
     from conftest import golden, load_weights
@@ -117,7 +123,8 @@ def test_training_matches_reference_golden_f8(dev):
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     m = m.to(dev)
     lr, wd, lam, amp, ks, sigma = g['hyper']
-    tr = StofNetTrainer(m, lr=lr, weight_decay=wd, lambda_value=lam, mask_amplitude=amp, kernel_size=int(ks), sigma=sigma)
+    tr = StofNetTrainer(m, lr=lr, weight_decay=wd, lambda_value=lam, mask_amplitude=amp, kernel_size=int(ks), sigma=sigma,
+                        precision=precision)
     frame, gt = torch.from_numpy(g['frame']).to(dev), torch.from_numpy(g['gt_true']).to(dev)
     loss, pred = tr.forward_backward(frame, gt)
     assert relerr(pred.cpu().numpy(), g['masks_pred']) < 1e-5
@@ -156,7 +163,7 @@ def test_loss_target_matches_reference_blur(dev):
     target, dpred = torch.empty_like(pred), torch.empty_like(pred)
     tmax = torch.empty(1, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float64, device=dev)
-    _lib.check(_lib.lib().stof_train_loss(_lib.ptr(pred), _lib.ptr(gt), gt.shape[1], _lib.ptr(taps), 4, pred.shape[1], 20.0, 1e-2,
+    _lib.check(_lib.lib().stof_train_loss(_lib.ptr(pred), _lib.ptr(gt), gt.shape[1], _lib.ptr(taps), 4, pred.shape[1], 20.0, 1e-2, 1.0,
                                           _lib.ptr(target), _lib.ptr(tmax), _lib.ptr(dpred), _lib.ptr(loss), _lib.stream_ptr(dev)),
                'stof_train_loss')
     assert np.abs(target.cpu().numpy() - g['masks_true_blur'].reshape(4, -1)).max() < 2e-6 * 20
