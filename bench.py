@@ -130,7 +130,7 @@ def train_bench(args, dev, dist, rank, world):
             'value': round(world * nb * args.steps / dt, 1), 'unit': 'waveforms/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.train_precision == 'fp32' else 'f32 (fwd/dgrad convs via split-fp16 x3 MFMA operands; wgrad exact f32)',
+            'dtype': 'f32' if args.train_precision == 'fp32' else 'f32 via split-fp16 x3 MFMA operands (hi+lo, fp32 accumulate) in fwd, dgrad and wgrad convolutions',
             'data': 'synthetic',
             'config': {'workload': f'C5 training step [{nb},1,{L}] -> [{nb},1,{L * R}] per GPU, Gaussian-mask loss, AdamW, '
                                    f'upsample_factor={R}', 'rows_per_gpu': nb, 'L': L, 'upsample_factor': R,

@@ -199,8 +199,8 @@ int stof_train_conv(const float* x, const float* w_tapmajor, const float* bias, 
  * dw/db; partial sums go through `workspace` and are added in a fixed order (bitwise reproducible).   */
 size_t stof_train_wgrad_workspace_bytes(int32_t cin, int32_t cout, int32_t K);
 int stof_train_wgrad(const float* x, const float* dy, float* dw, float* db, int64_t N, int64_t L,
-                     int32_t cin, int32_t cout, int32_t K, float out_scale, void* workspace, size_t workspace_bytes,
-                     void* stream);
+                     int32_t cin, int32_t cout, int32_t K, float out_scale, int32_t precision, void* workspace,
+                     size_t workspace_bytes, void* stream);
 /* conv1 (1->64, k9) + ReLU forward to channel-last, and its weight gradient (g masked by relu').    */
 int stof_train_conv1(const float* x, const float* w, const float* b, float* y, int64_t N, int64_t L, void* stream);
 int stof_train_conv1_wgrad(const float* x, const float* g, const float* saved, float* dw, float* db,

@@ -355,6 +355,116 @@ __global__ __launch_bounds__(256) void conv_wgrad_cl_kernel(const WgradParams p)
     if (blockIdx.z == 0 && tid < 64) p.dbpart[(size_t)blockIdx.x * p.cout_pad + o0 + tid] = dbs;
 }
 
+// f16x3 variant: both operands are split into fp16 hi + lo while they are staged in LDS (rows [t][64 hi | 64 lo]),
+// and the time-contiguous MFMA operand fragments come out of gfx950's transposing LDS read (ds_read_b64_tr_b16: per
+// 16-lane group a 4-row x 16-column block of 16-bit elements, delivered column-major), so the tap shift is just a
+// row offset.  64 time rows per tile; the 320-byte row stride makes the 4 rows x 64 B of a half-wave hit 64 distinct banks.
+constexpr int WG_ROWS_H = 64;
+constexpr int HSTRIDE = 320;
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ uint2 tr_read(const char* p) {
+    const fp16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p));
+    uint2 u;
+    __builtin_memcpy(&u, &r, 8);
+    return u;
+}
+template <int KMAX>
+__global__ __launch_bounds__(256) void conv_wgrad_f16x3_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) char dys[WG_ROWS_H * HSTRIDE];
+    __shared__ __attribute__((aligned(16))) char xs[(WG_ROWS_H + 8) * HSTRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mi = wave & 1, ni = wave >> 1, ln = lane & 31, lh = lane >> 5;
+    const int o0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
+    const int K = p.K, pad = K >> 1;
+    floatx16 acc[KMAX];
+#pragma unroll
+    for (int d = 0; d < KMAX; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+    float dbs = 0.f;
+    // lane's address inside a 4-row x 16-column block: row q, columns 4pq..4pq+3 of column block cb; k-group kg
+    const int q = (lane & 15) >> 2, pq = lane & 3, cb = (lane >> 4) & 1, kg = lane >> 5;
+    const char* const ap = dys + (8 * kg + q) * HSTRIDE + (32 * mi + 16 * cb + 4 * pq) * 2;
+    const char* const bp = xs + (8 * kg + q) * HSTRIDE + (32 * ni + 16 * cb + 4 * pq) * 2;
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+        const int n = tile / p.tiles_per_wf;
+        const int t0 = (tile - n * p.tiles_per_wf) * WG_ROWS_H;
+        __syncthreads();
+        for (int i = tid; i < WG_ROWS_H * 16; i += 256) {
+            const int r = i >> 4, qq = i & 15;
+            const int t = t0 + r, o = o0 + 4 * qq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < p.L) {
+                const float* src = p.dy + ((size_t)n * p.L + t) * p.cout + o;
+                if (o + 3 < p.cout) v = ld4(src);
+                else {
+                    if (o < p.cout) v.x = src[0];
+                    if (o + 1 < p.cout) v.y = src[1];
+                    if (o + 2 < p.cout) v.z = src[2];
+                }
+            }
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 8 * qq) = hi;
+            *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 128 + 8 * qq) = lo;
+        }
+        for (int i = tid; i < (WG_ROWS_H + 8) * 16; i += 256) {
+            const int r = i >> 4, qq = i & 15;
+            const int t = t0 - pad + r, c = c0 + 4 * qq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < p.L && r < WG_ROWS_H + K - 1) {
+                const float* src = p.x + ((size_t)n * p.L + t) * p.cin + c;
+                if (c + 3 < p.cin) v = ld4(src);
+                else {
+                    if (c < p.cin) v.x = src[0];
+                    if (c + 1 < p.cin) v.y = src[1];
+                    if (c + 2 < p.cin) v.z = src[2];
+                }
+            }
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<uint2*>(xs + r * HSTRIDE + 8 * qq) = hi;
+            *reinterpret_cast<uint2*>(xs + r * HSTRIDE + 128 + 8 * qq) = lo;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < WG_ROWS_H / 16; ++ks) {
+            const char* a = ap + ks * 16 * HSTRIDE;
+            const uint2 a0 = tr_read(a), a1 = tr_read(a + 4 * HSTRIDE);
+            const uint2 l0 = tr_read(a + 128), l1 = tr_read(a + 4 * HSTRIDE + 128);
+            const uint4 ah = make_uint4(a0.x, a0.y, a1.x, a1.y), al = make_uint4(l0.x, l0.y, l1.x, l1.y);
+#pragma unroll
+            for (int d = 0; d < KMAX; ++d) {
+                if (d >= K) continue;
+                const char* b = bp + (ks * 16 + d) * HSTRIDE;
+                const uint2 b0 = tr_read(b), b1 = tr_read(b + 4 * HSTRIDE);
+                const uint2 m0 = tr_read(b + 128), m1 = tr_read(b + 4 * HSTRIDE + 128);
+                acc[d] = mma16x3(ah, al, make_uint4(b0.x, b0.y, b1.x, b1.y), make_uint4(m0.x, m0.y, m1.x, m1.y), acc[d]);
+            }
+        }
+        if (blockIdx.z == 0 && tid < 64) {
+            float s = 0.f;
+            for (int r = 0; r < WG_ROWS_H; ++r) {
+                const _Float16* row = reinterpret_cast<const _Float16*>(dys + r * HSTRIDE);
+                s += (float)row[tid] + (float)row[64 + tid];
+            }
+            dbs += s;
+        }
+    }
+    float* part = p.part + (size_t)blockIdx.x * K * p.cout_pad * p.cin_pad;
+    const int c = c0 + 32 * ni + ln;
+#pragma unroll
+    for (int d = 0; d < KMAX; ++d) {
+        if (d >= K) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int o = o0 + 32 * mi + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            part[((size_t)d * p.cout_pad + o) * p.cin_pad + c] = acc[d][v];
+        }
+    }
+    if (blockIdx.z == 0 && tid < 64) p.dbpart[(size_t)blockIdx.x * p.cout_pad + o0 + tid] = dbs;
+}
+
 // dw[o][c][d] = sum_g part[g][d][o][c];  db[o] = sum_g dbpart[g][o]   (fixed summation order).
 // One work-group: 64 consecutive elements x 4 interleaved slices of g, combined through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
@@ -656,8 +766,8 @@ extern "C" size_t stof_train_wgrad_workspace_bytes(int32_t cin, int32_t cout, in
 }
 
 extern "C" int stof_train_wgrad(const float* x, const float* dy, float* dw, float* db, int64_t N, int64_t L,
-                                int32_t cin, int32_t cout, int32_t K, float out_scale, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                int32_t cin, int32_t cout, int32_t K, float out_scale, int32_t precision,
+                                void* workspace, size_t workspace_bytes, void* stream) {
     if (N < 0 || L < 0 || cin < 1 || cout < 1 || K < 1 || K > 7 || !(K & 1)) return STOF_ERR_BAD_ARG;
     if (!dw) return STOF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -671,7 +781,9 @@ extern "C" int stof_train_wgrad(const float* x, const float* dy, float* dw, floa
     WgradParams p;
     p.x = x; p.dy = dy; p.N = (int)N; p.L = (int)L; p.cin = cin; p.cout = cout; p.K = K;
     p.cin_pad = (cin + 63) / 64 * 64; p.cout_pad = (cout + 63) / 64 * 64;
-    p.tiles_per_wf = (int)((L + WG_ROWS - 1) / WG_ROWS);
+    if (precision != STOF_PREC_FP32 && precision != STOF_PREC_F16X3) return STOF_ERR_BAD_ARG;
+    const int rows = precision == STOF_PREC_F16X3 ? WG_ROWS_H : WG_ROWS;
+    p.tiles_per_wf = (int)((L + rows - 1) / rows);
     const int64_t tiles = N * p.tiles_per_wf;
     if (tiles > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
     p.total_tiles = (int)tiles;
@@ -680,9 +792,15 @@ extern "C" int stof_train_wgrad(const float* x, const float* dy, float* dw, floa
     p.part = static_cast<float*>(workspace);
     p.dbpart = p.part + (size_t)G * K * p.cout_pad * p.cin_pad;
     const dim3 grid((unsigned)G, (unsigned)(p.cout_pad / 64), (unsigned)(p.cin_pad / 64));
-    if (K <= 3) hipLaunchKernelGGL(conv_wgrad_cl_kernel<3>, grid, dim3(256), 0, s, p);
-    else if (K <= 5) hipLaunchKernelGGL(conv_wgrad_cl_kernel<5>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(conv_wgrad_cl_kernel<7>, grid, dim3(256), 0, s, p);
+    if (precision == STOF_PREC_F16X3) {
+        if (K <= 3) hipLaunchKernelGGL(conv_wgrad_f16x3_kernel<3>, grid, dim3(256), 0, s, p);
+        else if (K <= 5) hipLaunchKernelGGL(conv_wgrad_f16x3_kernel<5>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(conv_wgrad_f16x3_kernel<7>, grid, dim3(256), 0, s, p);
+    } else {
+        if (K <= 3) hipLaunchKernelGGL(conv_wgrad_cl_kernel<3>, grid, dim3(256), 0, s, p);
+        else if (K <= 5) hipLaunchKernelGGL(conv_wgrad_cl_kernel<5>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(conv_wgrad_cl_kernel<7>, grid, dim3(256), 0, s, p);
+    }
     const int total = K * p.cout_pad * p.cin_pad + p.cout_pad;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, p.part, p.dbpart, dw, db, G, K, cout, cin,
                        p.cout_pad, p.cin_pad, out_scale);

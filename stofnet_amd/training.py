@@ -40,7 +40,7 @@ class StofNetTrainer:
             raise NotImplementedError('the loss kernel implements the 7-tap blur of config.yaml:23')
         if precision not in ('fp32', 'f16x3'):
             raise ValueError("precision must be 'fp32' or 'f16x3'")
-        self.prec = 1 if precision == 'f16x3' else 0       # convolutions fwd + data gradient; weight gradients stay exact fp32
+        self.prec = 1 if precision == 'f16x3' else 0       # arithmetic of every 64/512-channel convolution: forward, data gradient, weight gradient
         self.model = model
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
         self.lam, self.amp = float(lambda_value), float(mask_amplitude)
@@ -97,7 +97,7 @@ class StofNetTrainer:
         if ws is None or ws.numel() < need:
             ws = self._wgrad_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         _lib.check(_lib.lib().stof_train_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(self.g[name + '.weight']),
-                                               _lib.ptr(self.g[name + '.bias']), n, L, cin, cout, K, 1.0 / self._gscale, _lib.ptr(ws),
+                                               _lib.ptr(self.g[name + '.bias']), n, L, cin, cout, K, 1.0 / self._gscale, self.prec, _lib.ptr(ws),
                                                ws.numel(),
                                                self._st()), 'stof_train_wgrad')
 
