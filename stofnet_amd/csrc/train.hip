@@ -67,7 +67,7 @@ struct ConvParams {
     const float* residual; // [N][L][cout] or nullptr : added after the activation (forward) / before the mask (backward)
     const float* saved;    // [N][L][cout] or nullptr : backward only, out *= act'(saved)
     float* y;              // [N][L][cout]
-    int N, L, cin, cout, K, act, tiles_per_wf;
+    int N, L, cin, cout, K, act, tiles_per_wf, total_tiles;
 };
 
 // One work-group: CT = 128 time rows x 64 output channels; loops over 64-wide input-channel blocks and
@@ -81,17 +81,11 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(16))) float ws[2][64 * TROWF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mi = wave & 1, ni = wave >> 1, ln = lane & 31, lh = lane >> 5;
-    const int n = blockIdx.x / p.tiles_per_wf;
-    const int t0 = (blockIdx.x - n * p.tiles_per_wf) * CT;
     const int o0 = blockIdx.y * 64;
     const int K = p.K, pad = K >> 1;
     const int rows = CT + K - 1;
-    const int nsteps = ((p.cin + 63) >> 6) * K;
-    floatx16 acc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const int ncb = (p.cin + 63) >> 6;
+    const int nsteps = ncb * K;
 
     float4 wreg[4];
     auto wfetch = [&](int s) {
@@ -103,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
             if constexpr (PREC == STOF_PREC_F16X3) {
                 // split layout [K][cout][cin_pad/64][64 hi | 64 lo halfs]: a 256-byte row per (tap, o, block) -- pure copy
                 if (o0 + o < p.cout)
-                    v = ld4(p.w + (((size_t)d * p.cout + o0 + o) * ((p.cin + 63) >> 6) + (c0 >> 6)) * 64 + 4 * q);
+                    v = ld4(p.w + (((size_t)d * p.cout + o0 + o) * ncb + (c0 >> 6)) * 64 + 4 * q);
             } else {
                 const int c = c0 + 4 * q;
                 if (o0 + o < p.cout) {
@@ -119,36 +113,63 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
             wreg[u] = v;
         }
     };
-    wfetch(0);
+    // activation tile rows t0-pad .. t0+CT-1+pad of channel block cb (zero outside the waveform / channel range):
+    // fetched HBM -> registers one (tile, block) ahead, so the latency hides behind the MFMAs of the current one
+    constexpr int NXR = ((CT + 8) * 16 + 255) / 256;
+    float4 xreg[NXR];
+    auto xfetch = [&](int tile, int cb) {
+        const int n = tile / p.tiles_per_wf;
+        const int t0 = (tile - n * p.tiles_per_wf) * CT;
+#pragma unroll
+        for (int u = 0; u < NXR; ++u) {
+            const int i = tid + 256 * u, r = i >> 4, q = i & 15;
+            const int t = t0 - pad + r, c = (cb << 6) + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && t >= 0 && t < p.L) {
+                const float* src = p.x + ((size_t)n * p.L + t) * p.cin + c;
+                if (c + 3 < p.cin) v = ld4(src);
+                else {
+                    if (c < p.cin) v.x = src[0];
+                    if (c + 1 < p.cin) v.y = src[1];
+                    if (c + 2 < p.cin) v.z = src[2];
+                }
+            }
+            xreg[u] = v;
+        }
+    };
+    if ((int)blockIdx.x < p.total_tiles) {
+        wfetch(0);
+        xfetch(blockIdx.x, 0);
+    }
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+    const int n = tile / p.tiles_per_wf;
+    const int t0 = (tile - n * p.tiles_per_wf) * CT;
+    const bool more = tile + (int)gridDim.x < p.total_tiles;
+    floatx16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
     for (int s = 0; s < nsteps; ++s) {
         const int cb = s / K, d = s - cb * K;
         if (d == 0) {
-            // activation tile rows t0-pad .. t0+CT-1+pad, channels 64cb.. (zero outside the waveform / channel range)
             __syncthreads();
-            const int c0 = cb << 6;
-            for (int i = tid; i < rows * 16; i += 256) {
-                const int r = i >> 4, q = i & 15;
-                const int t = t0 - pad + r, c = c0 + 4 * q;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t >= 0 && t < p.L) {
-                    const float* src = p.x + ((size_t)n * p.L + t) * p.cin + c;
-                    if (c + 3 < p.cin) v = ld4(src);
-                    else {
-                        if (c < p.cin) v.x = src[0];
-                        if (c + 1 < p.cin) v.y = src[1];
-                        if (c + 2 < p.cin) v.z = src[2];
-                    }
-                }
+#pragma unroll
+            for (int u = 0; u < NXR; ++u) {
+                const int i = tid + 256 * u, r = i >> 4, q = i & 15;
+                if (r >= CT + 8) continue;
                 if constexpr (PREC == STOF_PREC_F16X3) {
                     uint2 hi, lo;
-                    split4(v, hi, lo);
+                    split4(xreg[u], hi, lo);
                     char* row = reinterpret_cast<char*>(xs + r * TROWF);
                     *reinterpret_cast<uint2*>(row + 8 * q) = hi;
                     *reinterpret_cast<uint2*>(row + 128 + 8 * q) = lo;
                 } else {
-                    *reinterpret_cast<float4*>(xs + r * TROWF + 4 * q) = v;
+                    *reinterpret_cast<float4*>(xs + r * TROWF + 4 * q) = xreg[u];
                 }
             }
+            if (cb + 1 < ncb) xfetch(tile, cb + 1);
+            else if (more) xfetch(tile + gridDim.x, 0);
         }
         float* wb = ws[s & 1];
 #pragma unroll
@@ -158,6 +179,7 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
         }
         __syncthreads();
         if (s + 1 < nsteps) wfetch(s + 1);
+        else if (more) wfetch(0);
         const float* arow = wb + (32 * mi + ln) * TROWF + 4 * lh;
         const float* brow = xs + (64 * ni + ln + d) * TROWF + 4 * lh;
         if constexpr (PREC == STOF_PREC_F16X3) {
@@ -227,6 +249,7 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
             }
         }
     }
+    }   // persistent tile loop
 }
 
 // w_out[d][a][b] = w_in[b][a][K-1-d]  (torch layout (cout, cin, K) -> tap-major [K][cin][cout] flipped: dgrad)
@@ -386,12 +409,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x3_kernel(const WgradParams
     const int q = (lane & 15) >> 2, pq = lane & 3, cb = (lane >> 4) & 1, kg = lane >> 5;
     const char* const ap = dys + (8 * kg + q) * HSTRIDE + (32 * mi + 16 * cb + 4 * pq) * 2;
     const char* const bp = xs + (8 * kg + q) * HSTRIDE + (32 * ni + 16 * cb + 4 * pq) * 2;
-    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+    // The next tile's rows travel HBM -> registers while the MFMAs of the current tile run.
+    constexpr int NDY = WG_ROWS_H * 16 / 256, NX = ((WG_ROWS_H + 8) * 16 + 255) / 256;
+    float4 rdy[NDY], rx[NX];
+    auto fetch = [&](int tile) {
         const int n = tile / p.tiles_per_wf;
         const int t0 = (tile - n * p.tiles_per_wf) * WG_ROWS_H;
-        __syncthreads();
-        for (int i = tid; i < WG_ROWS_H * 16; i += 256) {
-            const int r = i >> 4, qq = i & 15;
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+            const int i = tid + 256 * u, r = i >> 4, qq = i & 15;
             const int t = t0 + r, o = o0 + 4 * qq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < p.L) {
@@ -403,13 +429,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x3_kernel(const WgradParams
                     if (o + 2 < p.cout) v.z = src[2];
                 }
             }
-            uint2 hi, lo;
-            split4(v, hi, lo);
-            *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 8 * qq) = hi;
-            *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 128 + 8 * qq) = lo;
+            rdy[u] = v;
         }
-        for (int i = tid; i < (WG_ROWS_H + 8) * 16; i += 256) {
-            const int r = i >> 4, qq = i & 15;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + 256 * u, r = i >> 4, qq = i & 15;
             const int t = t0 - pad + r, c = c0 + 4 * qq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t >= 0 && t < p.L && r < WG_ROWS_H + K - 1) {
@@ -421,12 +445,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x3_kernel(const WgradParams
                     if (c + 2 < p.cin) v.z = src[2];
                 }
             }
+            rx[u] = v;
+        }
+    };
+    if ((int)blockIdx.x < p.total_tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+            const int i = tid + 256 * u, r = i >> 4, qq = i & 15;
             uint2 hi, lo;
-            split4(v, hi, lo);
-            *reinterpret_cast<uint2*>(xs + r * HSTRIDE + 8 * qq) = hi;
-            *reinterpret_cast<uint2*>(xs + r * HSTRIDE + 128 + 8 * qq) = lo;
+            split4(rdy[u], hi, lo);
+            *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 8 * qq) = hi;
+            *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 128 + 8 * qq) = lo;
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + 256 * u, r = i >> 4, qq = i & 15;
+            if (r < WG_ROWS_H + 8) {
+                uint2 hi, lo;
+                split4(rx[u], hi, lo);
+                *reinterpret_cast<uint2*>(xs + r * HSTRIDE + 8 * qq) = hi;
+                *reinterpret_cast<uint2*>(xs + r * HSTRIDE + 128 + 8 * qq) = lo;
+            }
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < p.total_tiles) fetch(tile + gridDim.x);
 #pragma unroll
         for (int ks = 0; ks < WG_ROWS_H / 16; ++ks) {
             const char* a = ap + ks * 16 * HSTRIDE;
@@ -720,9 +764,14 @@ extern "C" int stof_train_conv(const float* x, const float* w_tapmajor, const fl
     p.x = x; p.w = w_tapmajor; p.bias = bias; p.residual = residual; p.saved = saved; p.y = y;
     p.N = (int)N; p.L = (int)L; p.cin = cin; p.cout = cout; p.K = K; p.act = act;
     p.tiles_per_wf = (int)((L + CT - 1) / CT);
-    const int64_t gx = N * p.tiles_per_wf;
-    if (gx > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)gx, (unsigned)((cout + 63) / 64));
+    const int64_t tiles = N * p.tiles_per_wf;
+    if (tiles > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    p.total_tiles = (int)tiles;
+    const int oblocks = (cout + 63) / 64;
+    int64_t gx = 512 / oblocks;                      // persistent: 2 work-groups per CU (71 KB of LDS each)
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = tiles;
+    const dim3 grid((unsigned)gx, (unsigned)oblocks);
     if (precision == STOF_PREC_F16X3)
         hipLaunchKernelGGL(conv_cl_kernel<STOF_PREC_F16X3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     else
@@ -753,16 +802,17 @@ extern "C" int stof_train_repack(const float* w, float* out, int32_t cout, int32
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
-static int wgrad_groups(int32_t cin, int32_t cout) {
+// persistent work-groups per (64 x 64) weight block: 3 per CU for the f16x3 kernel (43 KB of LDS), 2 for the fp32 one (70 KB)
+static int wgrad_groups(int32_t cin, int32_t cout, int32_t precision) {
     const int blocks = ((cout + 63) / 64) * ((cin + 63) / 64);
-    const int g = 512 / blocks;
+    const int g = (precision == STOF_PREC_F16X3 ? 768 : 512) / blocks;
     return g < 1 ? 1 : g;
 }
 
 extern "C" size_t stof_train_wgrad_workspace_bytes(int32_t cin, int32_t cout, int32_t K) {
     if (cin < 1 || cout < 1 || K < 1) return 0;
     const size_t cin_pad = (size_t)((cin + 63) / 64) * 64, cout_pad = (size_t)((cout + 63) / 64) * 64;
-    return (size_t)wgrad_groups(cin, cout) * ((size_t)K * cout_pad * cin_pad + cout_pad) * sizeof(float);
+    return (size_t)wgrad_groups(cin, cout, STOF_PREC_F16X3) * ((size_t)K * cout_pad * cin_pad + cout_pad) * sizeof(float);
 }
 
 extern "C" int stof_train_wgrad(const float* x, const float* dy, float* dw, float* db, int64_t N, int64_t L,
@@ -787,7 +837,7 @@ extern "C" int stof_train_wgrad(const float* x, const float* dy, float* dw, floa
     const int64_t tiles = N * p.tiles_per_wf;
     if (tiles > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
     p.total_tiles = (int)tiles;
-    int G = wgrad_groups(cin, cout);
+    int G = wgrad_groups(cin, cout, precision);
     if (G > tiles) G = (int)tiles;
     p.part = static_cast<float*>(workspace);
     p.dbpart = p.part + (size_t)G * K * p.cout_pad * p.cin_pad;
