@@ -203,8 +203,10 @@ int stof_train_wgrad(const float* x, const float* dy, float* dw, float* db, int6
                      size_t workspace_bytes, void* stream);
 /* conv1 (1->64, k9) + ReLU forward to channel-last, and its weight gradient (g masked by relu').    */
 int stof_train_conv1(const float* x, const float* w, const float* b, float* y, int64_t N, int64_t L, void* stream);
+size_t stof_train_conv1_wgrad_workspace_bytes(void);
 int stof_train_conv1_wgrad(const float* x, const float* g, const float* saved, float* dw, float* db,
-                           int64_t N, int64_t L, float out_scale, void* stream);
+                           int64_t N, int64_t L, float out_scale, void* workspace, size_t workspace_bytes,
+                           void* stream);
 /* SemiGlobalBlock pieces (models/stofnet.py:103,108-115): MaxPool1d(80) with arg-max, its routing
  * backward (times lrelu' of the pre-pool activation), nearest upsample + pad + add and its backward. */
 int stof_train_pool(const float* c, float* pooled, uint8_t* arg, int64_t N, int64_t L, int64_t P, int32_t C, void* stream);

@@ -567,10 +567,10 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 }
 
 // dW1[ch][d] += sum_t g'[t][ch] x[t+d-4], db1[ch] += sum_t g'[t][ch], g' = g * relu'(saved conv1 output)
+constexpr int C1_COPIES = 64;
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                          const float* __restrict__ saved, float* __restrict__ dw,
-                                                          float* __restrict__ db, int N, int L, int rows_per_block,
-                                                          float out_scale) {
+                                                          const float* __restrict__ saved,
+                                                          float* __restrict__ copies, int N, int L, int rows_per_block) {
     __shared__ float red[4][64][10];
     const int tid = threadIdx.x, ch = tid & 63, part = tid >> 6;
     const int r0 = blockIdx.x * rows_per_block;                 // N*L < 2^31 is checked by the caller
@@ -594,12 +594,23 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     for (int d = 0; d < 10; ++d) red[part][ch][d] = acc[d];
     __syncthreads();
     if (part == 0) {
+        float* copy = copies + (blockIdx.x % C1_COPIES) * 640;       // spread the atomics over replicated accumulators
 #pragma unroll
         for (int d = 0; d < 10; ++d) {
-            const float s = ((red[0][ch][d] + red[1][ch][d]) + (red[2][ch][d] + red[3][ch][d])) * out_scale;
-            if (d < 9) atomicAdd(dw + ch * 9 + d, s); else atomicAdd(db + ch, s);
+            const float s = (red[0][ch][d] + red[1][ch][d]) + (red[2][ch][d] + red[3][ch][d]);
+            atomicAdd(copy + ch * 10 + d, s);
         }
     }
+}
+
+__global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ copies, float* __restrict__ dw, float* __restrict__ db,
+                                          float out_scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (ch, d)
+    if (i >= 640) return;
+    float s = 0.f;
+    for (int c = 0; c < C1_COPIES; ++c) s += copies[c * 640 + i];
+    const int ch = i / 10, d = i - ch * 10;
+    if (d < 9) dw[ch * 9 + d] = s * out_scale; else db[ch] = s * out_scale;
 }
 
 // MaxPool1d(80, 80) over time of c[N][L][C] -> pooled[N][P][C] with the arg-max offset (first maximum)
@@ -705,16 +716,15 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
                                                         const float* __restrict__ tmax, float amplitude, float lambda,
                                                         long long count, float grad_scale, float* __restrict__ dpred,
                                                         double* __restrict__ loss) {
-    const long long i = blockIdx.x * 256ll + threadIdx.x;
     const float tm = tmax[0];
     const double inv = 1.0 / (double)count;
     double part = 0.0;
-    if (i < count) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += gridDim.x * 256ll) {
         const float pv = pred[i];
         const float tv = target[i] / tm * amplitude;             // main.py:230-231: /= max, then *= amplitude
         target[i] = tv;
         const float diff = pv - tv;
-        part = ((double)diff * diff + (double)lambda * fabsf(pv)) * inv;
+        part += ((double)diff * diff + (double)lambda * fabsf(pv)) * inv;
         const float sg = pv > 0.f ? 1.f : (pv < 0.f ? -1.f : 0.f);
         dpred[i] = (float)((2.0 * diff + (double)lambda * sg) * inv) * grad_scale;   // power-of-two scale: exact
     }
@@ -866,15 +876,27 @@ extern "C" int stof_train_conv1(const float* x, const float* w, const float* b, 
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
+extern "C" size_t stof_train_conv1_wgrad_workspace_bytes(void) { return (size_t)C1_COPIES * 640 * sizeof(float); }
+
 extern "C" int stof_train_conv1_wgrad(const float* x, const float* g, const float* saved, float* dw, float* db, int64_t N,
-                                      int64_t L, float out_scale, void* stream) {
+                                      int64_t L, float out_scale, void* workspace, size_t workspace_bytes, void* stream) {
     if (N < 0 || L < 0) return STOF_ERR_BAD_ARG;
-    if (N == 0 || L == 0) return STOF_OK;
-    if (!x || !g || !saved || !dw || !db) return STOF_ERR_BAD_ARG;
+    if (!dw || !db) return STOF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N == 0 || L == 0) {
+        if (hipMemsetAsync(dw, 0, 64 * 9 * sizeof(float), s) != hipSuccess || hipMemsetAsync(db, 0, 64 * sizeof(float), s) != hipSuccess)
+            return STOF_ERR_HIP;
+        return STOF_OK;
+    }
+    if (!x || !g || !saved || !workspace) return STOF_ERR_BAD_ARG;
+    if (workspace_bytes < stof_train_conv1_wgrad_workspace_bytes()) return STOF_ERR_WORKSPACE;
     if (N * L > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    float* copies = static_cast<float*>(workspace);
+    if (hipMemsetAsync(copies, 0, stof_train_conv1_wgrad_workspace_bytes(), s) != hipSuccess) return STOF_ERR_HIP;
     const int rows_per_block = 256;
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)((N * L + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, g, saved, dw, db, (int)N, (int)L, rows_per_block, out_scale);
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)((N * L + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s,
+                       x, g, saved, copies, (int)N, (int)L, rows_per_block);
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(3), dim3(256), 0, s, copies, dw, db, out_scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
@@ -940,7 +962,8 @@ extern "C" int stof_train_loss(const float* pred, const int64_t* gt_idx, int64_t
     }
     hipLaunchKernelGGL(loss_target_kernel, dim3((unsigned)N), dim3(256), (size_t)M * sizeof(float), s,
                        reinterpret_cast<const long long*>(gt_idx), (int)G, taps7, target, (int)N, (int)M, tmax);
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(blocks_for(N * M)), dim3(256), 0, s, pred, target, tmax, amplitude, lambda,
+    const unsigned lblocks = blocks_for(N * M) < 2048u ? blocks_for(N * M) : 2048u;   // one double atomic per block
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(lblocks), dim3(256), 0, s, pred, target, tmax, amplitude, lambda,
                        (long long)(N * M), grad_scale, dpred, loss);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }

@@ -185,9 +185,10 @@ class StofNetTrainer:
                 g_a1 = self._conv(gc, bwd[sg + 'contract_conv'], None, 512, 64, 5, residual=g_x0)
             else:
                 g_a1 = g_x0
+            ws1 = torch.empty(lib.stof_train_conv1_wgrad_workspace_bytes(), dtype=torch.uint8, device=self.dev)
             _lib.check(lib.stof_train_conv1_wgrad(_lib.ptr(x), _lib.ptr(g_a1), _lib.ptr(a1), _lib.ptr(self.g['conv1.weight']),
-                                                  _lib.ptr(self.g['conv1.bias']), n, L, 1.0 / self._gscale, st),
-                       'stof_train_conv1_wgrad')
+                                                  _lib.ptr(self.g['conv1.bias']), n, L, 1.0 / self._gscale, _lib.ptr(ws1),
+                                                  ws1.numel(), st), 'stof_train_conv1_wgrad')
         return loss[0], pred.view(n, 1, L * r)
 
     def loss(self, masks_pred: torch.Tensor, gt_true: torch.Tensor) -> torch.Tensor:
