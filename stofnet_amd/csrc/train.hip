@@ -392,7 +392,7 @@ __device__ __forceinline__ uint2 tr_read(const char* p) {
     return u;
 }
 template <int KMAX>
-__global__ __launch_bounds__(256) void conv_wgrad_f16x3_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradParams p) {
     __shared__ __attribute__((aligned(16))) char dys[WG_ROWS_H * HSTRIDE];
     __shared__ __attribute__((aligned(16))) char xs[(WG_ROWS_H + 8) * HSTRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
