@@ -190,7 +190,13 @@ __device__ void run_stage(float2*& cur, float2*& other, const float2* tw, int n,
 
 // One work-group transforms rows blockIdx.x, blockIdx.x + gridDim.x, ... so the twiddle table is
 // brought into LDS once per work-group (TW_LDS) instead of being fetched from L2 in every stage.
-template <bool TW_LDS>
+//
+// PAIR (even n): two real rows ride one complex transform, z = x1 + i x2.  The filter is linear, so
+// ifft(H fft(z)) = a1 + i a2 with a_j = x_j + i v_j the analytic signals (for even n the filter
+// returns the real part unchanged), i.e. Re = x1 - v2, Im = v1 + x2, hence v1 = Im - x2 and
+// v2 = x1 - Re: half the transforms per row.  For odd n (Q6: bin n/2 not doubled) the real part is
+// not preserved and every row gets its own transform.
+template <bool TW_LDS, bool PAIR>
 __global__ __launch_bounds__(512) void hilbert_kernel(const float* __restrict__ x, const float2* __restrict__ twg,
                                                       const float* __restrict__ hf, const FftPlan plan,
                                                       long long nrows, float* __restrict__ env,
@@ -205,12 +211,14 @@ __global__ __launch_bounds__(512) void hilbert_kernel(const float* __restrict__ 
         for (int i = threadIdx.x; i < n; i += blockDim.x) twl[i] = twg[i];
         tw = twl;
     }
-    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+    constexpr int RPW = PAIR ? 2 : 1;                              // rows per transform
+    for (long long row = (long long)blockIdx.x * RPW; row < nrows; row += (long long)gridDim.x * RPW) {
         float2* cur = buf0;
         float2* other = buf1;
         const float* xr = x + row * (size_t)n;
+        const bool second = PAIR && row + 1 < nrows;
         __syncthreads();                                           // previous row fully written out
-        for (int i = threadIdx.x; i < n; i += blockDim.x) cur[i] = make_float2(xr[i], 0.f);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) cur[i] = make_float2(xr[i], second ? xr[n + i] : 0.f);
         __syncthreads();
 
         // forward DIF: block length shrinks n -> 1
@@ -233,9 +241,22 @@ __global__ __launch_bounds__(512) void hilbert_kernel(const float* __restrict__ 
         }
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const float2 v = cur[i];
-            if (env) env[row * (size_t)n + i] = hypotf(v.x, v.y);
-            if (re) re[row * (size_t)n + i] = v.x;
-            if (im) im[row * (size_t)n + i] = v.y;
+            if (!PAIR) {
+                if (env) env[row * (size_t)n + i] = hypotf(v.x, v.y);
+                if (re) re[row * (size_t)n + i] = v.x;
+                if (im) im[row * (size_t)n + i] = v.y;
+            } else {
+                const float x1 = xr[i], x2 = second ? xr[n + i] : 0.f;
+                const float v1 = v.y - x2, v2 = x1 - v.x;
+                if (env) env[row * (size_t)n + i] = hypotf(x1, v1);
+                if (re) re[row * (size_t)n + i] = x1;
+                if (im) im[row * (size_t)n + i] = v1;
+                if (second) {
+                    if (env) env[(row + 1) * (size_t)n + i] = hypotf(x2, v2);
+                    if (re) re[(row + 1) * (size_t)n + i] = x2;
+                    if (im) im[(row + 1) * (size_t)n + i] = v2;
+                }
+            }
         }
     }
 }
@@ -261,14 +282,17 @@ extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, fl
     const bool tw_lds = data_lds + (size_t)n * sizeof(float2) <= (size_t)LDS_BYTES;
     const size_t lds = data_lds + (tw_lds ? (size_t)n * sizeof(float2) : 0);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hilbert_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&hilbert_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    const bool pair = (n % 2 == 0);
+    using Kern = void (*)(const float*, const float2*, const float*, const FftPlan, long long, float*, float*, float*);
+    const Kern kern = tw_lds ? (pair ? &hilbert_kernel<true, true> : &hilbert_kernel<true, false>)
+                             : (pair ? &hilbert_kernel<false, true> : &hilbert_kernel<false, false>);
+    static bool attr_done[4] = {false, false, false, false};
+    const int ki = (tw_lds ? 2 : 0) + (pair ? 1 : 0);
+    if (!attr_done[ki]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+            hipSuccess)
             return STOF_ERR_HIP;
-        attr_done = true;
+        attr_done[ki] = true;
     }
     float2* tw = static_cast<float2*>(workspace);
     float* hf = reinterpret_cast<float*>(tw + n);
@@ -278,12 +302,8 @@ extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, fl
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 4) per_cu = 4;                                          // 512 threads x 4 = 32 waves per CU
     int64_t grid = 256 * per_cu;
-    if (grid > N) grid = N;
-    if (tw_lds)
-        hipLaunchKernelGGL(hilbert_kernel<true>, dim3((unsigned)grid), dim3(512), lds, stream, x, tw, hf, plan,
-                           (long long)N, env, re, im);
-    else
-        hipLaunchKernelGGL(hilbert_kernel<false>, dim3((unsigned)grid), dim3(512), lds, stream, x, tw, hf, plan,
-                           (long long)N, env, re, im);
+    const int64_t units = pair ? (N + 1) / 2 : N;
+    if (grid > units) grid = units;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, x, tw, hf, plan, (long long)N, env, re, im);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
