@@ -2,7 +2,7 @@
 //
 //   sgb_contract_pool : x -> relu(conv1) -> contract_conv 64->512 k5 (MFMA) -> lrelu
 //                       -> max-pool 80  => pooled[N][P][512]        (models/stofnet.py:45,100-103)
-//   sgb_expand        : pooled -> expand_conv 512->64 k5 -> lrelu   => sgb[N][P][64]   (:106-107)
+//   expand (train.hip conv_cl_kernel, stream mode): pooled -> expand_conv 512->64 k5 -> lrelu => sgb[N][P][64] (:106-107)
 //   body_sweep        : x, sgb -> relu(conv1) + upsample/pad(sgb) (:45,108-115) -> conv2..conv12
 //                       with the residual pattern of :51-62 -> conv_last -> SampleShuffle1D store
 //                       (:65, utils/sample_shuffle.py:10-28)        => y[N][L*r]
@@ -24,6 +24,14 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "stof_common.h"
+
+// expand_conv 512->64 k5 on the pooled grid + lrelu runs on the channel-last MFMA conv of train.hip in stream mode (the P
+// pooled columns of every waveform followed by 2 zero gap rows form one long row sequence, so the 128-row tiles are full).
+namespace stof {
+int launch_conv_cl(const float* x, const float* w, const float* bias, const float* residual, const float* saved, float* y,
+                   int64_t N, int64_t L, int32_t cin, int32_t cout, int32_t K, int32_t act, int32_t precision,
+                   int32_t period, int32_t valid_len, hipStream_t stream);
+}
 
 using namespace stof;
 
@@ -696,60 +704,6 @@ __global__ __launch_bounds__(256, SGB_WAVES_PER_SIMD) void sgb_contract_pool_ker
     }
 }
 
-// expand_conv 512->64 k5 on the pooled grid + lrelu (0.2 % of the FLOPs): plain fp32 FMA.
-// One work-group = 16 pooled columns of one waveform.  The K = 5 x 512 reduction is split over
-// the 4 waves (128 input channels each) so every weight is fetched once per work-group and
-// feeds 16 FMAs; the partial sums meet in LDS.
-constexpr int EXP_COLS = 16;
-__global__ __launch_bounds__(256) void sgb_expand_kernel(const float* __restrict__ pooled,
-                                                         const float* __restrict__ ew,
-                                                         const float* __restrict__ ebias,
-                                                         float* __restrict__ sgb, int N, int P,
-                                                         int blocks_per_wf) {
-    __shared__ __attribute__((aligned(16))) float tile[(EXP_COLS + 4) * NF_SGB];
-    __shared__ float part[4][EXP_COLS][NF];
-    const int tid = threadIdx.x;
-    const int n = blockIdx.x / blocks_per_wf;
-    const int wbase = (blockIdx.x - n * blocks_per_wf) * EXP_COLS;
-    for (int i = tid; i < (EXP_COLS + 4) * NF_SGB / 4; i += 256) {
-        const int col = i / (NF_SGB / 4), c4 = i - col * (NF_SGB / 4);
-        const int w = wbase - 2 + col;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (w >= 0 && w < P) v = ld4(pooled + ((size_t)n * P + w) * NF_SGB + 4 * c4);
-        st4(tile + col * NF_SGB + 4 * c4, v);
-    }
-    __syncthreads();
-    const int oc = tid & 63, kq = tid >> 6;           // wave kq reduces input channels [128 kq, 128 kq + 128)
-    float acc[EXP_COLS];
-#pragma unroll
-    for (int k = 0; k < EXP_COLS; ++k) acc[k] = 0.f;
-    for (int d = 0; d < 5; ++d) {
-        const float* wp = ew + ((size_t)d * NF_SGB + 128 * kq) * NF + oc;
-        const float* tp = tile + d * NF_SGB + 128 * kq;
-#pragma unroll 4
-        for (int ch = 0; ch < 128; ++ch) {
-            const float w = wp[(size_t)ch * NF];
-#pragma unroll
-            for (int k = 0; k < EXP_COLS; ++k) acc[k] = fmaf(w, tp[k * NF_SGB + ch], acc[k]);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < EXP_COLS; ++k) part[kq][k][oc] = acc[k];
-    __syncthreads();
-    const float b = ebias[oc];
-#pragma unroll
-    for (int kk = 0; kk < EXP_COLS / 4; ++kk) {
-        const int k = 4 * kk + kq;                    // each wave finishes 4 of the 16 columns
-        const int w = wbase + k;
-        if (w < P) {
-            // fixed summation order over the four K-slices: bitwise reproducible
-            float v = ((part[0][k][oc] + part[1][k][oc]) + (part[2][k][oc] + part[3][k][oc])) + b;
-            v = v > 0.f ? v : 0.01f * v;
-            sgb[((size_t)n * P + w) * NF + oc] = v;
-        }
-    }
-}
-
 constexpr int BODY_S = 192, BODY_RING = 256, BODY_RAWRING = 256;
 constexpr int64_t SUB_BATCH = 4096;      // rows whose SGB maps share one workspace
 
@@ -811,9 +765,11 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
             hipLaunchKernelGGL((sgb_contract_pool_kernel<PREC, SGB_NW>), dim3((unsigned)(nb * sp.tiles_per_wf)),
                                dim3(256), sgb_lds_bytes(), stream, sp);
             if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[1]), stream);
-            const int bpw = (int)((P + EXP_COLS - 1) / EXP_COLS);
-            hipLaunchKernelGGL(sgb_expand_kernel, dim3((unsigned)(nb * bpw)), dim3(256), 0, stream,
-                               pooled, ew, ebias, sgb, (int)nb, (int)P, bpw);
+            {
+                const int st = stof::launch_conv_cl(pooled, ew, ebias, nullptr, nullptr, sgb, 1, nb * (P + 2), NF_SGB, NF, 5,
+                                                    /*act = leaky ReLU*/ 2, PREC, (int)(P + 2), (int)P, stream);
+                if (st != STOF_OK) return st;
+            }
             if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[2]), stream);
         } else if (ev) {
             (void)hipEventRecord(static_cast<hipEvent_t>(events[1]), stream);

@@ -117,10 +117,21 @@ extern "C" int stof_pack_weights(const stof_net_desc* desc, const float* const* 
                     cc += SGB_CHUNK_F;
                 }
         const float* we = params[28];                                   // (64, 512, 5)
+        // operand image of the channel-last MFMA conv (train.hip conv_cl_kernel): tap-major rows per output channel
         for (int t = 0; t < 5; ++t)
-            for (int c = 0; c < NF_SGB; ++c)
-                for (int o = 0; o < NF; ++o)
-                    base[h.off_ew + ((uint64_t)t * NF_SGB + c) * NF + o] = we[(o * NF_SGB + c) * 5 + t];
+            for (int o = 0; o < NF; ++o)
+                for (int c = 0; c < NF_SGB; ++c) {
+                    const float v = we[(o * NF_SGB + c) * 5 + t];
+                    if (desc->precision == STOF_PREC_FP32) {
+                        base[h.off_ew + ((uint64_t)t * NF + o) * NF_SGB + c] = v;
+                    } else {                                            // [t][o][c/64][64 hi | 64 lo] fp16
+                        _Float16* row = reinterpret_cast<_Float16*>(base + h.off_ew) +
+                                        (((uint64_t)t * NF + o) * (NF_SGB / 64) + c / 64) * 128;
+                        const _Float16 hi = (_Float16)v;
+                        row[c % 64] = hi;
+                        row[64 + c % 64] = (_Float16)(v - (float)hi);
+                    }
+                }
         for (int o = 0; o < NF; ++o) base[h.off_ebias + o] = params[29][o];
     }
     return STOF_OK;

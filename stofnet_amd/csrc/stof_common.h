@@ -45,7 +45,8 @@ struct PackedHeader {
     uint64_t off_body;            // BODY_NCHUNK chunks of BODY_CHUNK_F floats
     uint64_t off_cbias;           // [512] contract_conv bias
     uint64_t off_cchunks;         // SGB_NCHUNK chunks of SGB_CHUNK_F floats
-    uint64_t off_ew;              // expand_conv weights as [5 taps][512 ch][64 oc]
+    uint64_t off_ew;              // expand_conv operand of conv_cl_kernel: fp32 [5 taps][64 oc][512 ch];
+                                  // f16x3 [5][64][8 blocks][64 hi | 64 lo] fp16 (same float count)
     uint64_t off_ebias;           // [64]
     uint64_t total_floats;
     uint8_t reserved[256 - 4 * 2 - 4 * 4 - 8 * 8];

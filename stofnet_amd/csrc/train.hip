@@ -68,6 +68,10 @@ struct ConvParams {
     const float* saved;    // [N][L][cout] or nullptr : backward only, out *= act'(saved)
     float* y;              // [N][L][cout]
     int N, L, cin, cout, K, act, tiles_per_wf, total_tiles;
+    // stream mode (period > 0): the rows are one sequence of N' blocks of `period` rows of which the first `valid_len`
+    // map to rows of a dense [N'][valid_len][C] tensor and the rest are zero gaps (>= K/2 rows, so blocks do not see
+    // each other); used by the inference path for the SemiGlobalBlock expand conv on the pooled grid
+    int period, valid_len;
 };
 
 // One work-group: CT = 128 time rows x 64 output channels; loops over 64-wide input-channel blocks and
@@ -75,7 +79,9 @@ struct ConvParams {
 // the weight fragments.  The weight tile of the next (block, tap) step is fetched from L2 into registers
 // while the MFMAs of the current one run, and lands in the other half of a double-buffered LDS tile.
 constexpr int CT = 128;
-template <int PREC>
+// BLOCKSUM: every 64-channel input block is summed in an accumulator of its own and folded into the total afterwards
+// (shorter fp32 chains; used for the 2560-term reduction of the inference expand conv, where MFMA time is not the limit)
+template <int PREC, bool BLOCKSUM = false>
 __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(16))) float xs[(CT + 8) * TROWF];
     __shared__ __attribute__((aligned(16))) float ws[2][64 * TROWF];
@@ -125,8 +131,15 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
             const int i = tid + 256 * u, r = i >> 4, q = i & 15;
             const int t = t0 - pad + r, c = (cb << 6) + 4 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows && t >= 0 && t < p.L) {
-                const float* src = p.x + ((size_t)n * p.L + t) * p.cin + c;
+            size_t rowidx = (size_t)n * p.L + t;
+            bool ok = r < rows && t >= 0 && t < p.L;
+            if (p.period > 0 && ok) {
+                const int nn = t / p.period, pp = t - nn * p.period;
+                ok = pp < p.valid_len;
+                rowidx = (size_t)nn * p.valid_len + pp;
+            }
+            if (ok) {
+                const float* src = p.x + rowidx * p.cin + c;
                 if (c + 3 < p.cin) v = ld4(src);
                 else {
                     if (c < p.cin) v.x = src[0];
@@ -150,9 +163,24 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    floatx16 tot[2];
+    if constexpr (BLOCKSUM) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tot[j][e] = 0.f;
+    }
     for (int s = 0; s < nsteps; ++s) {
         const int cb = s / K, d = s - cb * K;
         if (d == 0) {
+            if constexpr (BLOCKSUM) {
+                if (cb > 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { tot[j][e] += acc[j][e]; acc[j][e] = 0.f; }
+                }
+            }
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < NXR; ++u) {
@@ -202,13 +230,24 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
             }
         }
     }
+    if constexpr (BLOCKSUM) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] += tot[j][e];
+    }
     // epilogue: lane (ln, lh) holds time row t0 + 64ni + 32j + ln, channels o0 + 32mi + 8gg + 4lh + e
     const bool vec = (p.cout & 3) == 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int t = t0 + 64 * ni + 32 * j + ln;
         if (t >= p.L) continue;
-        const size_t rowoff = ((size_t)n * p.L + t) * p.cout;
+        size_t rowoff = ((size_t)n * p.L + t) * p.cout;
+        if (p.period > 0) {
+            const int nn = t / p.period, pp = t - nn * p.period;
+            if (pp >= p.valid_len) continue;
+            rowoff = ((size_t)nn * p.valid_len + pp) * p.cout;
+        }
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
             const int o = o0 + 32 * mi + 8 * gg + 4 * lh;
@@ -763,6 +802,38 @@ inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
+namespace stof {
+// Shared by the training entry point and by the inference forward (SemiGlobalBlock expand conv, stream mode).
+int launch_conv_cl(const float* x, const float* w, const float* bias, const float* residual, const float* saved, float* y,
+                   int64_t N, int64_t L, int32_t cin, int32_t cout, int32_t K, int32_t act, int32_t precision,
+                   int32_t period, int32_t valid_len, hipStream_t stream) {
+    ConvParams p;
+    p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.saved = saved; p.y = y;
+    p.N = (int)N; p.L = (int)L; p.cin = cin; p.cout = cout; p.K = K; p.act = act;
+    p.period = period; p.valid_len = valid_len;
+    p.tiles_per_wf = (int)((L + CT - 1) / CT);
+    const int64_t tiles = N * p.tiles_per_wf;
+    if (tiles > 0x7fffffffLL || N * L > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    p.total_tiles = (int)tiles;
+    const int oblocks = (cout + 63) / 64;
+    int64_t gx = 512 / oblocks;                      // persistent: 2 work-groups per CU (71 KB of LDS each)
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = tiles;
+    const dim3 grid((unsigned)gx, (unsigned)oblocks);
+    if (period > 0) {
+        if (precision == STOF_PREC_F16X3)
+            hipLaunchKernelGGL((conv_cl_kernel<STOF_PREC_F16X3, true>), grid, dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL((conv_cl_kernel<STOF_PREC_FP32, true>), grid, dim3(256), 0, stream, p);
+    } else if (precision == STOF_PREC_F16X3) {
+        hipLaunchKernelGGL((conv_cl_kernel<STOF_PREC_F16X3, false>), grid, dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((conv_cl_kernel<STOF_PREC_FP32, false>), grid, dim3(256), 0, stream, p);
+    }
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+}  // namespace stof
+
 extern "C" int stof_train_conv(const float* x, const float* w_tapmajor, const float* bias, const float* residual,
                                const float* saved, float* y, int64_t N, int64_t L, int32_t cin, int32_t cout,
                                int32_t K, int32_t act, int32_t precision, void* stream) {
@@ -770,23 +841,8 @@ extern "C" int stof_train_conv(const float* x, const float* w_tapmajor, const fl
     if (precision != STOF_PREC_FP32 && precision != STOF_PREC_F16X3) return STOF_ERR_BAD_ARG;
     if (N == 0 || L == 0) return STOF_OK;
     if (!x || !w_tapmajor || !y) return STOF_ERR_BAD_ARG;
-    ConvParams p;
-    p.x = x; p.w = w_tapmajor; p.bias = bias; p.residual = residual; p.saved = saved; p.y = y;
-    p.N = (int)N; p.L = (int)L; p.cin = cin; p.cout = cout; p.K = K; p.act = act;
-    p.tiles_per_wf = (int)((L + CT - 1) / CT);
-    const int64_t tiles = N * p.tiles_per_wf;
-    if (tiles > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
-    p.total_tiles = (int)tiles;
-    const int oblocks = (cout + 63) / 64;
-    int64_t gx = 512 / oblocks;                      // persistent: 2 work-groups per CU (71 KB of LDS each)
-    if (gx < 1) gx = 1;
-    if (gx > tiles) gx = tiles;
-    const dim3 grid((unsigned)gx, (unsigned)oblocks);
-    if (precision == STOF_PREC_F16X3)
-        hipLaunchKernelGGL(conv_cl_kernel<STOF_PREC_F16X3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    else
-        hipLaunchKernelGGL(conv_cl_kernel<STOF_PREC_FP32>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+    return stof::launch_conv_cl(x, w_tapmajor, bias, residual, saved, y, N, L, cin, cout, K, act, precision, 0, 0,
+                                static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t stof_train_repack_floats(int32_t cout, int32_t cin, int32_t K, int32_t transpose_flip, int32_t precision) {

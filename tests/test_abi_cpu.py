@@ -112,8 +112,15 @@ def test_pack_layout(lib, r, sgs, prec):
                     dense = unpack_chunk(cc[ocb, t, hh], 4, prec)
                     ref = wc[128 * ocb:128 * ocb + 128, 32 * hh:32 * hh + 32, t]
                     assert close(dense, ref)
-        ew = f[off:off + 5 * 512 * 64].reshape(5, 512, 64); off += 5 * 512 * 64
-        assert np.array_equal(ew, sd['semi_global_block.expand_conv.weight'].transpose(2, 1, 0))
+        we = sd['semi_global_block.expand_conv.weight']                      # (64, 512, 5)
+        if prec == 0:       # fp32 operand of the channel-last MFMA conv: [tap][oc][ch]
+            ew = f[off:off + 5 * 512 * 64].reshape(5, 64, 512)
+            assert np.array_equal(ew, we.transpose(2, 0, 1))
+        else:               # f16x3: [tap][oc][ch/64][64 hi | 64 lo] fp16
+            hl = f[off:off + 5 * 512 * 64].view(np.float16).reshape(5, 64, 8, 2, 64).astype(np.float64)
+            dense = (hl[:, :, :, 0] + hl[:, :, :, 1]).reshape(5, 64, 512)
+            assert close(dense, we.transpose(2, 0, 1))
+        off += 5 * 512 * 64
         assert np.array_equal(f[off:off + 64], sd['semi_global_block.expand_conv.bias']); off += 64
     assert off == f.size
 
