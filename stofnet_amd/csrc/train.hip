@@ -868,10 +868,11 @@ extern "C" int stof_train_repack(const float* w, float* out, int32_t cout, int32
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
-// persistent work-groups per (64 x 64) weight block: 3 per CU for the f16x3 kernel (43 KB of LDS), 2 for the fp32 one (70 KB)
+// persistent work-groups per (64 x 64) weight block: 2 per CU (fp32: 70 KB of LDS each; f16x3: 198 VGPRs -> 2 waves per SIMD)
 static int wgrad_groups(int32_t cin, int32_t cout, int32_t precision) {
+    (void)precision;
     const int blocks = ((cout + 63) / 64) * ((cin + 63) / 64);
-    const int g = (precision == STOF_PREC_F16X3 ? 768 : 512) / blocks;
+    const int g = 512 / blocks;
     return g < 1 ? 1 : g;
 }
 
