@@ -52,7 +52,8 @@ typedef struct stof_net_desc {
     int32_t upsample_factor;     /* r: conv_last has r output channels (1..64)                  */
     int32_t semi_global_scale;   /* 80 = SemiGlobalBlock present, 1 = ablation without it       */
     int32_t precision;           /* STOF_PREC_*                                                 */
-    int32_t reserved;
+    int32_t seg_policy;           /* body sweep at small batches: 0 = automatic (waveforms are cut into 2^k segments
+                                   * with +-38 rows of context while fewer than one per CU exists); k+1 forces 2^k   */
 } stof_net_desc;
 
 #define STOF_PREC_FP32 0          /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), parity baseline     */

@@ -29,7 +29,7 @@ NUM_PARAMS = 30
 
 class NetDesc(ctypes.Structure):
     _fields_ = [('upsample_factor', ctypes.c_int32), ('semi_global_scale', ctypes.c_int32),
-                ('precision', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('precision', ctypes.c_int32), ('seg_policy', ctypes.c_int32)]
 
 
 class StofnetLibraryMissing(ImportError):

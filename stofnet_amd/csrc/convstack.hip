@@ -145,6 +145,10 @@ struct BodyParams {
     const float* bias;     // [13][64]
     const float* chunks;   // [BODY_NCHUNK][BODY_CHUNK_F] fragment-ordered weights
     int N, L, r, P, rem_half, wf_per_wg;
+    // Small batches: every waveform is cut into 2^nseg_log2 segments of seg_len rows that are swept as independent
+    // 'virtual waveforms' with `halo` real rows of context on both sides (the stack's receptive field is +-38), so
+    // that the CUs are not left idle.  N counts virtual waveforms; nseg_log2 = 0, seg_len = L, halo = 0 is the plain case.
+    int nseg_log2, seg_len, halo;
     unsigned long long* stamps;   // diagnostic builds (-DSTOF_STAMPS) only: [wg][wave][8] cycle sums
     int* status;                  // optional: bit 0 set if a non-finite output was produced (f16x3 range overflow)
 };
@@ -181,9 +185,17 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
     const int n0 = blockIdx.x * p.wf_per_wg;
     const int n1 = min(p.N, n0 + p.wf_per_wg);
     if (n0 >= n1) return;
-    const int L = p.L, r = p.r;
+    const int Ltrue = p.L, r = p.r;
+    const int L = p.seg_len + 2 * p.halo;        // rows of one (virtual) waveform in the stream
     const int Lp = L + GAP;
     const int gend = (n1 - n0) * Lp;             // local stream rows [0, gend)
+    const int seg_mask = (1 << p.nseg_log2) - 1;
+    const bool seg_mode = p.nseg_log2 > 0;
+    // (virtual waveform, local row) -> (waveform, time); rows whose time falls outside [0, Ltrue) are padding
+    auto vmap = [&](int nv, int tl, int& n, int& tt) {
+        n = nv >> p.nseg_log2;
+        tt = (nv & seg_mask) * p.seg_len - p.halo + tl;
+    };
 
     // ---- one-time setup: zero rings, biases to LDS, conv1 taps to registers
     for (int i = tid; i < Lds::RAW + RAWRING; i += 256) smem[i] = 0.f;
@@ -229,13 +241,17 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             int t = tb + it;
             int nl = nb;
             if (t >= Lp) { t -= Lp; nl += 1; }             // NIT < Lp: at most one wrap
-            const bool ok = (g >= 0) && (g < gend) && (t < L);
+            int nw, tw;
+            vmap(n0 + nl, t, nw, tw);
+            const bool ok = (g >= 0) && (g < gend) && (t < L) && (tw >= 0) && (tw < Ltrue);
             float4 sg = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.sgb != nullptr && ok) {
-                const int pos = t - p.rem_half;
+                const int pos = tw - p.rem_half;
                 if (pos >= 0 && pos < SGB_SCALE * p.P) {
-                    const int wid = (n0 + nl) * p.P + pos / SGB_SCALE;      // global window id
-                    sg = ld4(sgl + (wid & 7) * NF + 4 * cq);                // staged by the step prologue
+                    const int wid = nw * p.P + pos / SGB_SCALE;             // global window id
+                    // staged in LDS by the step prologue; segments start anywhere inside a window, which the
+                    // prologue's probe rows do not cover, so the (throughput-insensitive) segment mode reads L2
+                    sg = seg_mode ? ld4(p.sgb + (size_t)wid * NF + 4 * cq) : ld4(sgl + (wid & 7) * NF + 4 * cq);
                 }
             }
             float v[4];
@@ -263,10 +279,12 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             const int g = Fn + 4 - S + tid;
             int nl, t;
             decode_row(nB, tB, 4 + tid, nl, t);
-            if (g < gend && t < L) raw_next = p.x[(size_t)(n0 + nl) * L + t];
+            int nw, tw;
+            vmap(n0 + nl, t, nw, tw);
+            if (g < gend && t < L && tw >= 0 && tw < Ltrue) raw_next = p.x[(size_t)nw * Ltrue + tw];
         }
         sg_slot = -1;
-        if (p.sgb != nullptr) {
+        if (p.sgb != nullptr && !seg_mode) {
             const int q = tid >> 6;
             const int off = q == 3 ? S - 1 : 80 * q;
             const int g = Fn - S + off;
@@ -281,7 +299,11 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
         }
     };
     static_assert(S <= 240 && S > 160, "probe offsets {0, 80, 160, S-1} assume 160 < S <= 240");
-    if (tid < 4 && tid < L) rawr[tid] = p.x[(size_t)n0 * L + tid];      // rows 0..3 precede the first fetch
+    if (tid < 4 && tid < L) {                                            // rows 0..3 precede the first fetch
+        int nw, tw;
+        vmap(n0, tid, nw, tw);
+        if (tw >= 0 && tw < Ltrue) rawr[tid] = p.x[(size_t)nw * Ltrue + tw];
+    }
     fetch_step(S, 0, 0);
 
     // ---- weight fragments: registers, fetched two chunks ahead of use
@@ -440,7 +462,9 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                     const int g = R0 + off;
                     int nk, tk;
                     decode_row(nR, tR, off, nk, tk);
-                    tvalid[k] = (g >= 0) && (g < gend) && (tk < L);
+                    int nw, tw;
+                    vmap(n0 + nk, tk, nw, tw);
+                    tvalid[k] = (g >= 0) && (g < gend) && (tk < L) && (tw >= 0) && (tw < Ltrue);
                     tslot[k] = (g & (RING - 1)) * ROWB + (32 * mi + 4 * lh) * (PREC == STOF_PREC_FP32 ? 4 : 2);
                 }
                 constexpr int MAINC = BODY_CHUNKS_K7 - TAILC;
@@ -595,7 +619,14 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                     const int off = 32 * (NT * ni + k) + ln;
                     const int g = R0 + off;
                     decode_row(nR, tR, off, nn[k], tt[k]);
-                    valid[k] = (g >= 0) && (g < gend) && (tt[k] < L);
+                    int nw, tw;
+                    vmap(n0 + nn[k], tt[k], nw, tw);
+                    valid[k] = (g >= 0) && (g < gend) && (tt[k] < L) && (tw >= 0) && (tw < Ltrue);
+                    if (last) {                                      // outputs: only the segment's own rows
+                        valid[k] = valid[k] && (tt[k] >= p.halo) && (tt[k] < p.halo + p.seg_len);
+                        nn[k] = nw - n0;
+                        tt[k] = tw;
+                    }
                     slot[k] = g & (RING - 1);
                     allvalid = allvalid && valid[k];
                 }
@@ -665,7 +696,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
                         if (!valid[k]) continue;
-                        float* const orow = p.y + ((size_t)(n0 + nn[k]) * L + tt[k]) * r;
+                        float* const orow = p.y + ((size_t)(n0 + nn[k]) * Ltrue + tt[k]) * r;
 #pragma unroll
                         for (int gg = 0; gg < 4; ++gg) {
                             const int c0 = 32 * mi + 8 * gg + 4 * lh;
@@ -865,6 +896,7 @@ constexpr size_t sgb_lds_bytes() {
 template <int PREC>
 int launch_forward(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y, int64_t N,
                    int64_t L, void* workspace, hipStream_t stream, void* const* events, int32_t* status) {
+    const int force_nseg_log2 = desc->seg_policy > 0 ? desc->seg_policy - 1 : -1;
     const int r = desc->upsample_factor;
     const bool has_sgb = desc->semi_global_scale != 1;
     const int64_t P = L / SGB_SCALE;
@@ -932,13 +964,23 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         bp.N = (int)nb; bp.L = (int)L; bp.r = r; bp.P = (int)P; bp.rem_half = (int)(rem / 2);
         bp.stamps = nullptr;
         bp.status = status;
+        // Small batches: cut every waveform into 2^k segments (each swept with +-38 rows of real context, the
+        // receptive field of conv1 + 11 x k7 + conv_last) until there is about one virtual waveform per CU.
+        bp.nseg_log2 = 0;
+        int64_t nseg = 1;
+        while (nb * nseg * 2 <= ncu && L / (nseg * 2) >= BODY_S) { nseg *= 2; bp.nseg_log2 += 1; }
+        if (force_nseg_log2 >= 0) { bp.nseg_log2 = force_nseg_log2; nseg = (int64_t)1 << force_nseg_log2; }
+        bp.seg_len = (int)((L + nseg - 1) / nseg);
+        bp.halo = nseg > 1 ? 38 : 0;
+        const int64_t nv = nb * nseg;                     // virtual waveforms
+        bp.N = (int)nv;
 #ifdef STOF_STAMPS
         if (workspace) bp.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + (size_t)(nb * P * (NF_SGB + NF)) * sizeof(float) + 256);
 #endif
         // one persistent work-group per CU, each sweeping a contiguous run of waveforms
-        int64_t wgs = nb < ncu ? nb : ncu;
-        bp.wf_per_wg = (int)((nb + wgs - 1) / wgs);
-        wgs = (nb + bp.wf_per_wg - 1) / bp.wf_per_wg;
+        int64_t wgs = nv < ncu ? nv : ncu;
+        bp.wf_per_wg = (int)((nv + wgs - 1) / wgs);
+        wgs = (nv + bp.wf_per_wg - 1) / bp.wf_per_wg;
         hipLaunchKernelGGL((body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>), dim3((unsigned)wgs), dim3(256),
                            Lds::BYTES, stream, bp);
         if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[3]), stream);

@@ -30,6 +30,7 @@ static int check_desc(const stof_net_desc* d) {
     if (d->upsample_factor < 1 || d->upsample_factor > 64) return STOF_ERR_UNSUPPORTED;
     if (d->semi_global_scale != 1 && d->semi_global_scale != SGB_SCALE) return STOF_ERR_UNSUPPORTED;
     if (d->precision != STOF_PREC_FP32 && d->precision != STOF_PREC_F16X3) return STOF_ERR_UNSUPPORTED;
+    if (d->seg_policy < 0 || d->seg_policy > 6) return STOF_ERR_UNSUPPORTED;
     return STOF_OK;
 }
 

@@ -91,7 +91,9 @@ class StofNet(nn.Module):
         return ps
 
     def _desc(self):
-        return _lib.NetDesc(int(self.upsample_factor), int(self.semi_global_scale), _PRECISIONS[self.precision], 0)
+        # 4th field: segment policy of the body sweep (0 = automatic; k+1 forces 2^k segments per waveform -- tests)
+        return _lib.NetDesc(int(self.upsample_factor), int(self.semi_global_scale), _PRECISIONS[self.precision],
+                            int(getattr(self, '_seg_policy', 0)))
 
     def _packed_weights(self, device):
         ps = self._param_list()

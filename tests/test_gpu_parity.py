@@ -146,6 +146,25 @@ def test_forward_batch_and_workgroup_splits(dev, precision):
 
 
 @pytest.mark.parametrize('precision', PRECISIONS)
+@pytest.mark.parametrize('L', [2000, 1536, 2578, 960])
+def test_small_batch_segment_mode_is_bit_identical(dev, precision, L):
+    """Small batches are swept as 2^k overlapping segments per waveform (+-38 rows of context) so the CUs are not idle:
+    every output row sees the same arithmetic, so forcing 1, 2, 4 or 8 segments must give identical bits, and the
+    automatic choice must match the oracle."""
+    sd = load_weights('different-armadillo')
+    x = torch.from_numpy(synth.synth_echo(3, L, seed=17)).to(dev)
+    outs = []
+    for policy in (1, 2, 3, 4, 0):                        # 1, 2, 4, 8 segments, automatic
+        m = make_model(dev, sd, 4, precision=precision)
+        m._seg_policy = policy
+        outs.append(m(x))
+    for y in outs[1:]:
+        assert torch.equal(outs[0], y)
+    ref = so.stofnet_forward(sd, x.cpu().numpy(), 4, 80).numpy()
+    assert rel_err(outs[-1].cpu().numpy(), ref) < (MAP_TOL if precision == 'fp32' else MAP_TOL_F16X3_VS_REF)
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
 def test_forward_full_size_row_independence(dev, precision):
     """Full-size property check at C2 shape [4096,1,2000]: every row equals the same row
     computed in a small batch (no cross-row leakage at full occupancy)."""
