@@ -964,11 +964,25 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         bp.N = (int)nb; bp.L = (int)L; bp.r = r; bp.P = (int)P; bp.rem_half = (int)(rem / 2);
         bp.stamps = nullptr;
         bp.status = status;
-        // Small batches: cut every waveform into 2^k segments (each swept with +-38 rows of real context, the
-        // receptive field of conv1 + 11 x k7 + conv_last) until there is about one virtual waveform per CU.
+        // Cut every waveform into 2^k segments (each swept with +-38 rows of real context, the receptive field of
+        // conv1 + 11 x k7 + conv_last) when that shortens the sweep: small batches, batches that do not fill the CUs evenly.
+        // k is chosen to minimise the sweep steps of the busiest work-group (it also evens out batches that are not a
+        // multiple of the CU count); ties go to fewer segments.
         bp.nseg_log2 = 0;
-        int64_t nseg = 1;
-        while (nb * nseg * 2 <= ncu && L / (nseg * 2) >= BODY_S) { nseg *= 2; bp.nseg_log2 += 1; }
+        {
+            int64_t best = -1;
+            for (int k = 0; k <= 5; ++k) {
+                const int64_t ns = (int64_t)1 << k;
+                if (k > 0 && L / ns < BODY_S / 2) break;
+                const int64_t lv = (L + ns - 1) / ns + (k > 0 ? 76 : 0);
+                const int64_t nvk = nb * ns;
+                const int64_t w = nvk < ncu ? nvk : ncu;
+                const int64_t per = (nvk + w - 1) / w;
+                const int64_t steps = (per * (lv + GAP) - GAP + LAG_LAST + BODY_S - 1) / BODY_S;
+                if (best < 0 || steps < best) { best = steps; bp.nseg_log2 = k; }
+            }
+        }
+        int64_t nseg = (int64_t)1 << bp.nseg_log2;
         if (force_nseg_log2 >= 0) { bp.nseg_log2 = force_nseg_log2; nseg = (int64_t)1 << force_nseg_log2; }
         bp.seg_len = (int)((L + nseg - 1) / nseg);
         bp.halo = nseg > 1 ? 38 : 0;
