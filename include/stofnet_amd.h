@@ -151,8 +151,8 @@ int stof_gradpeak_gradient(const float* env, int64_t N, int64_t L, int32_t grad_
                            void* stream);
 /* Stage 2: threshold crossings + pairing per row.  echoes[N, cap, 3] =
  * (onset, peak, env[peak]) for the first `cap` echoes of each row, counts[N]
- * exact; flags[0] is set to 1 if some row has edges but no surviving
- * candidate (Q9: the reference then returns an empty tensor for the batch).  */
+ * exact; flags[2] (zeroed by the caller): flags[0] is set to 1 if some row has edges but no surviving
+ * candidate (Q9: the reference then returns an empty tensor for the batch), flags[1] = max(counts).  */
 int stof_gradpeak_pair(const float* env, const float* grad, int64_t N, int64_t L,
                        float thres_pos, int32_t ival_min, int32_t ival_max,
                        float* echoes, int64_t cap, int32_t* counts, int32_t* flags,

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void gradpeak_pair_kernel(const float* __restr
     if (lane == 0) {
         counts[row] = nout;
         if (any_ap && any_am && nout == 0) atomicOr(&flags[0], 1);   // Q9 (:54-55)
+        if (nout > 0) atomicMax(&flags[1], nout);                    // Kmax of the batch (one host read for both)
     }
 }
 

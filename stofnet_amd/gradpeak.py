@@ -25,6 +25,17 @@ def gaussian_kernel_1d(sigma: float, num_sigmas: float = 3.) -> torch.Tensor:
     return torch.from_numpy(k * (1.0 / k.sum()))
 
 
+_TAPS = {}
+
+
+def _taps_on(device, grad_step):
+    """Gaussian taps for sigma = (2 g - 1) / 6 as a float32 device tensor (cached per device and step)."""
+    key = (str(device), int(grad_step))
+    if key not in _TAPS:
+        _TAPS[key] = gaussian_kernel_1d((grad_step * 2 - 1) / 6).to(device, torch.float32)
+    return _TAPS[key]
+
+
 def grad_peak_detect(data, grad_step: int = None, threshold: float = None, ival_smin: int = None,
                      ival_smax: int = None):
     """models/gradpeak.py:8-68 -> [N, Kmax, 3] = (onset, peak, amplitude), zero padded."""
@@ -32,8 +43,7 @@ def grad_peak_detect(data, grad_step: int = None, threshold: float = None, ival_
     env = data.detach().contiguous().float()
     n, L = env.shape
     grad_step = grad_step if grad_step is not None else 2
-    taps64 = gaussian_kernel_1d((grad_step * 2 - 1) / 6)
-    taps = taps64.to(env.device, torch.float32)
+    taps = _taps_on(env.device, grad_step)
     radius = (taps.numel() - 1) // 2
     lib = _lib.lib()
     grad = torch.empty_like(env)
@@ -60,7 +70,7 @@ def grad_peak_detect(data, grad_step: int = None, threshold: float = None, ival_
     def run(cap):
         echoes = torch.zeros((n, cap, 3), dtype=torch.float32, device=env.device)
         counts = torch.empty((n,), dtype=torch.int32, device=env.device)
-        flags = torch.zeros((1,), dtype=torch.int32, device=env.device)
+        flags = torch.zeros((2,), dtype=torch.int32, device=env.device)
         with torch.cuda.device(env.device):
             _lib.check(lib.stof_gradpeak_pair(_lib.ptr(env), _lib.ptr(grad), n, L, thres_pos, ival[0], ival[1],
                                               _lib.ptr(echoes), cap, _lib.ptr(counts), _lib.ptr(flags), stream),
@@ -68,8 +78,8 @@ def grad_peak_detect(data, grad_step: int = None, threshold: float = None, ival_
         return echoes, counts, flags
 
     echoes, counts, flags = run(_CAP)
-    kmax = int(counts.max()) if n else 0
-    if int(flags[0]):
+    q9, kmax = (int(v) for v in flags.cpu()) if n else (0, 0)        # the one host sync (reference: :35-66 python loop)
+    if q9:
         # Q9 (models/gradpeak.py:54-55): the reference returns an empty [3, 0] tensor for the whole batch
         return torch.tensor([[], [], []])
     if kmax > _CAP:
