@@ -1007,6 +1007,7 @@ int forward_impl(const stof_net_desc* desc, const void* packed_dev, const float*
                  void* workspace, size_t workspace_bytes, void* stream_, void* const* events, int32_t* status) {
     if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     if (desc->precision != STOF_PREC_FP32 && desc->precision != STOF_PREC_F16X3) return STOF_ERR_UNSUPPORTED;
+    if (desc->seg_policy < 0 || desc->seg_policy > 6) return STOF_ERR_UNSUPPORTED;
     const int r = desc->upsample_factor;
     if (r < 1 || r > 64) return STOF_ERR_UNSUPPORTED;
     const bool has_sgb = desc->semi_global_scale != 1;
