@@ -22,6 +22,7 @@
 //   STOF_PREC_F16X3 operands split x = hi + lo in fp16 (|err| ~ 2^-22 |x|), three
 //                   v_mfma_f32_32x32x16_f16 passes hi*hi + hi*lo + lo*hi, fp32 accumulate
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "stof_common.h"
 
@@ -50,6 +51,7 @@ constexpr int SGB_WAVES_PER_SIMD = (SGB_NW <= 2) ? 2 : 1;   // small tiles: two 
 constexpr int ROWB = ROWF * 4;    // activation row stride in bytes
 
 typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int layer_lag(int j) { return j <= 11 ? 3 * j : LAG_LAST; }
@@ -144,6 +146,7 @@ struct BodyParams {
     const float* c1;       // [64][10]
     const float* bias;     // [13][64]
     const float* chunks;   // [BODY_NCHUNK][BODY_CHUNK_F] fragment-ordered weights
+    const float* last16;   // f16x3, r <= 16: conv_last as 16x16x32 MFMA operands (stof_common.h), else nullptr
     int N, L, r, P, rem_half, wf_per_wg;
     // Small batches: every waveform is cut into 2^nseg_log2 segments of seg_len rows that are swept as independent
     // 'virtual waveforms' with `halo` real rows of context on both sides (the stack's receptive field is +-38), so
@@ -591,6 +594,65 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                 STAMP_ADD(2);
                 continue;
             }
+            if constexpr (PREC == STOF_PREC_F16X3) {
+                if (p.last16 != nullptr) {
+                    // conv_last with r <= 16: one 16-channel output tile on v_mfma_f32_16x16x32_f16 instead of two
+                    // 32-channel tiles (of which 22+ channels are padding): every wave takes 48 rows of the step,
+                    // a quarter of the MFMA work.  D[out-ch][time]: lane (j = lane & 15, q4 = lane >> 4) ends up
+                    // with output channels 4 q4 .. 4 q4 + 3 of time row j.
+                    const int j16 = lane & 15, q4 = lane >> 4;
+                    const uint4* lw = reinterpret_cast<const uint4*>(p.last16) + lane;
+                    uint4 wh[BODY_CHUNKS_LAST], wl[BODY_CHUNKS_LAST];
+#pragma unroll
+                    for (int cc = 0; cc < BODY_CHUNKS_LAST; ++cc) { wh[cc] = lw[(cc * 2) * 64]; wl[cc] = lw[(cc * 2 + 1) * 64]; }
+#pragma unroll
+                    for (int f = 0; f < FRAGS_PER_CHUNK; ++f) { wf[0][f] = wload(0, f); wf[1][f] = wload(1, f); }   // next step
+                    const float4 b4 = ld4(biasl + 12 * 64 + 4 * q4);
+                    floatx4 a16[3];
+                    bool bad = false;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        a16[k][0] = b4.x; a16[k][1] = b4.y; a16[k][2] = b4.z; a16[k][3] = b4.w;
+                        const int off = 48 * wave + 16 * k + j16;
+#pragma unroll
+                        for (int cc = 0; cc < BODY_CHUNKS_LAST; ++cc) {
+                            const int d = cc >> 1, hh = cc & 1;
+                            const char* row = src + ((R0 + off + d - 1) & (RING - 1)) * ROWB + (32 * hh + 8 * q4) * 2;
+                            const half8 bh = as_h8(ldq(row)), bl = as_h8(ldq(row + 128));
+                            a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wh[cc]), bh, a16[k], 0, 0, 0);
+                            a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wh[cc]), bl, a16[k], 0, 0, 0);
+                            a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wl[cc]), bh, a16[k], 0, 0, 0);
+                        }
+                    }
+                    STAMP_ADD(4);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int off = 48 * wave + 16 * k + j16;
+                        const int g = R0 + off;
+                        int nk, tk, nw, tw;
+                        decode_row(nR, tR, off, nk, tk);
+                        vmap(n0 + nk, tk, nw, tw);
+                        const bool ok = (g >= 0) && (g < gend) && (tk < L) && (tw >= 0) && (tw < Ltrue) &&
+                                        (tk >= p.halo) && (tk < p.halo + p.seg_len);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bad = bad || !(fabsf(a16[k][e]) <= 3.0e38f);
+                        if (!ok || 4 * q4 >= r) continue;
+                        float* const orow = p.y + ((size_t)nw * Ltrue + tw) * r + 4 * q4;
+                        if ((r & 3) == 0) {
+                            st4(orow, make_float4(a16[k][0], a16[k][1], a16[k][2], a16[k][3]));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (4 * q4 + e < r) orow[e] = a16[k][e];
+                        }
+                    }
+                    if (p.status != nullptr && __any(bad) && lane == 0) atomicOr(p.status, 1);
+                    STAMP_ADD(5);
+                    __syncthreads();
+                    STAMP_ADD(2);
+                    continue;
+                }
+            }
             run_chunks(std::integral_constant<int, BODY_CHUNKS_LAST>{});
 #else
             if (last) run_chunks(std::integral_constant<int, BODY_CHUNKS_LAST>{});
@@ -908,6 +970,10 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
     const float* c1 = base + off;      off += 64 * 10;
     const float* bias = base + off;    off += 13 * 64;
     const float* body = base + off;    off += (uint64_t)BODY_NCHUNK * BODY_CHUNK_F;
+    const float* last16 = nullptr;
+    if (PREC == STOF_PREC_F16X3 && r <= 16) { last16 = base + off; off += LAST16_F; }
+    static const bool no_last16 = getenv("STOF_NO_LAST16") != nullptr;     // diagnostic A/B switch
+    const float* last16_use = no_last16 ? nullptr : last16;
     const float* cbias = base + off;   off += NF_SGB;
     const float* cchunks = base + off; off += (uint64_t)SGB_NCHUNK * SGB_CHUNK_F;
     const float* ew = base + off;      off += 5ull * NF_SGB * NF;
@@ -960,7 +1026,7 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         }
         BodyParams bp;
         bp.x = xb; bp.sgb = (has_sgb && P > 0) ? sgb : nullptr; bp.y = yb;
-        bp.c1 = c1; bp.bias = bias; bp.chunks = body;
+        bp.c1 = c1; bp.bias = bias; bp.chunks = body; bp.last16 = last16_use;
         bp.N = (int)nb; bp.L = (int)L; bp.r = r; bp.P = (int)P; bp.rem_half = (int)(rem / 2);
         bp.stamps = nullptr;
         bp.status = status;

@@ -16,6 +16,7 @@ static void layout(const stof_net_desc* d, PackedHeader* h) {
     h->off_c1 = off;      off += 64 * 10;
     h->off_bias = off;    off += 13 * 64;
     h->off_body = off;    off += (uint64_t)BODY_NCHUNK * BODY_CHUNK_F;
+    if (d->precision == STOF_PREC_F16X3 && d->upsample_factor <= 16) { h->off_last16 = off; off += LAST16_F; }
     if (d->semi_global_scale != 1) {
         h->off_cbias = off;   off += NF_SGB;
         h->off_cchunks = off; off += (uint64_t)SGB_NCHUNK * SGB_CHUNK_F;
@@ -106,6 +107,23 @@ extern "C" int stof_pack_weights(const stof_net_desc* desc, const float* const* 
                 pack_chunk(ck, 2, 0, w, co, NF, K, t, hh, desc->precision);
                 ck += BODY_CHUNK_F;
             }
+    }
+    if (h.off_last16) {
+        // conv_last (r <= 16 output channels) as the A operand of v_mfma_f32_16x16x32_f16: lane (i = lane & 15,
+        // kg = lane >> 4) holds output channel i, input channels 32 hh + 8 kg .. + 7 of tap t; rows >= r are zero
+        const float* w = params[24];                                    // (r, 64, 3)
+        _Float16* dst = reinterpret_cast<_Float16*>(base + h.off_last16);
+        for (int t = 0; t < 3; ++t)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int o = lane & 15, ch = 32 * hh + 8 * (lane >> 4) + e;
+                        const float v = o < r ? w[((size_t)o * NF + ch) * 3 + t] : 0.f;
+                        const _Float16 hi = (_Float16)v;
+                        const size_t cc = (size_t)t * 2 + hh;
+                        dst[((cc * 2 + 0) * 64 + lane) * 8 + e] = hi;
+                        dst[((cc * 2 + 1) * 64 + lane) * 8 + e] = (_Float16)(v - (float)hi);
+                    }
     }
     if (desc->semi_global_scale != 1) {
         for (int c = 0; c < NF_SGB; ++c) base[h.off_cbias + c] = params[27][c];

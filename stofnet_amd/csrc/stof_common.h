@@ -49,9 +49,12 @@ struct PackedHeader {
                                   // f16x3 [5][64][8 blocks][64 hi | 64 lo] fp16 (same float count)
     uint64_t off_ebias;           // [64]
     uint64_t total_floats;
-    uint8_t reserved[256 - 4 * 2 - 4 * 4 - 8 * 8];
+    uint64_t off_last16;          // f16x3 and r <= 16 only (else 0): conv_last as 16x16x32 MFMA operands,
+                                  // [6 chunks (tap, 32-ch half)][hi | lo][64 lanes][8 fp16] = LAST16_F floats
+    uint8_t reserved[256 - 4 * 2 - 4 * 4 - 8 * 9];
 };
 static_assert(sizeof(PackedHeader) == 256, "header must be 256 bytes");
 constexpr uint32_t PACK_MAGIC = 0x464F5453u;
+constexpr int LAST16_F = 6 * 2 * 64 * 4;      // floats of the off_last16 section
 
 }  // namespace stof

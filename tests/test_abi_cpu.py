@@ -102,6 +102,17 @@ def test_pack_layout(lib, r, sgs, prec):
                 assert close(dense, ref)
                 c += 1
     assert c == 160
+    if prec == 1 and r <= 16:
+        # conv_last as v_mfma_f32_16x16x32_f16 A operands: [tap*2 + half][hi | lo][lane][8 fp16], lane = (out-ch, k-group)
+        sec = f[off:off + 6 * 2 * 64 * 4].view(np.float16).reshape(6, 2, 64, 8).astype(np.float64); off += 6 * 2 * 64 * 4
+        w = sd['conv_last.weight']
+        dense = sec[:, 0] + sec[:, 1]                                          # [chunk][lane][8]
+        for cc in range(6):
+            t, hh = cc // 2, cc % 2
+            for lane in range(64):
+                o, kg = lane & 15, lane >> 4
+                ref = w[o, 32 * hh + 8 * kg:32 * hh + 8 * kg + 8, t] if o < r else np.zeros(8)
+                assert close(dense[cc, lane], ref)
     if sgs != 1:
         assert np.array_equal(f[off:off + 512], sd['semi_global_block.contract_conv.bias']); off += 512
         cc = f[off:off + 40 * 4096].reshape(4, 5, 2, 4096); off += 40 * 4096
