@@ -69,8 +69,10 @@ def host_cores():
     return min(cores, 64)
 
 
-def cpu_baseline(sd, r, sample_rows=256, reps=3):
-    """The oracle (oracle/stofnet_oracle.py, PyTorch CPU fp32) on a bounded sample."""
+def cpu_baseline(sd, r, y_gpu=None, idx_gpu=None, sample_rows=256, reps=3):
+    """The oracle (oracle/stofnet_oracle.py, PyTorch CPU fp32) on a bounded sample: its speed on the host cores, and
+    -- as the checker -- the parity of the timed GPU outputs on the same rows (the input of rank 0 is the same seed)."""
+    from oracle import pickers_oracle as po
     from oracle import stofnet_oracle as so
     from oracle import synth
     cores = host_cores()
@@ -80,11 +82,23 @@ def cpu_baseline(sd, r, sample_rows=256, reps=3):
         so.stofnet_forward(sd, x[:16], r)          # warm-up
         t0 = time.perf_counter()
         for _ in range(reps):
-            so.stofnet_forward(sd, x, r)
+            y_ref = so.stofnet_forward(sd, x, r)
         dt = (time.perf_counter() - t0) / reps
-    return {'value': round(sample_rows / dt, 2), 'unit': 'waveforms/s', 'cores': cores, 'kind': 'port',
-            'sample': f'[{sample_rows},1,{L}] fp32, upsample_factor={r}, PyTorch-CPU oracle, '
-                      f'{reps} reps after warm-up, torch {torch.__version__}'}
+    out = {'value': round(sample_rows / dt, 2), 'unit': 'waveforms/s', 'cores': cores, 'kind': 'port',
+           'sample': f'[{sample_rows},1,{L}] fp32, upsample_factor={r}, PyTorch-CPU oracle, '
+                     f'{reps} reps after warm-up, torch {torch.__version__}'}
+    if y_gpu is not None:
+        y_ref = y_ref.numpy()
+        ref_idx = po.maxima_positions(y_ref, 20, None)       # int64 [K, 2] (row, index), arg-max mode
+        first = np.full(sample_rows, -1, np.int64)
+        for row, t in ref_idx[::-1]:
+            first[row] = t
+        got = idx_gpu[:sample_rows, 0].cpu().numpy().astype(np.int64)
+        out['parity_on_sample'] = {
+            'onset_index_mae': float(np.abs(got - first).mean()),
+            'onset_index_mismatches': int((got != first).sum()),
+            'max_rel_err_maps': float(np.abs(y_gpu[:sample_rows].cpu().numpy() - y_ref).max() / np.abs(y_ref).max())}
+    return out
 
 
 def train_bench(args, dev, dist, rank, world):
@@ -312,7 +326,7 @@ def main():
                        'fp32_exact_mode': fp32_extra},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sd, R)
+            out['cpu_baseline'] = cpu_baseline(sd, R, y, idx)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
