@@ -91,7 +91,8 @@ def train(model, frames, gt, cfg):
     if world > 1 and not dist.is_initialized():
         dist.init_process_group('nccl', device_id=torch.device(cfg.device))
     tr = StofNetTrainer(model, lr=cfg.lr, weight_decay=cfg.weight_decay, lambda_value=cfg.lambda_value,
-                        mask_amplitude=cfg.mask_amplitude, kernel_size=cfg.kernel_size, sigma=cfg.sigma)
+                        mask_amplitude=cfg.mask_amplitude, kernel_size=cfg.kernel_size, sigma=cfg.sigma,
+                        precision=cfg.train_precision)
     r, bs = int(cfg.upsample_factor), int(cfg.batch_size)
     n_val = max(bs, int(frames.shape[0] * 0.1) // bs * bs)              # held-out tail for early stopping
     tr_x, tr_gt = frames[:-n_val], gt[:-n_val]

@@ -170,13 +170,14 @@ def test_loss_target_matches_reference_blur(dev):
     assert abs(float(loss[0]) - float(g['loss0'])) < 2e-6 * float(g['loss0'])
 
 
-def test_main_entry_point_trains_and_saves_checkpoint(dev, tmp_path):
+@pytest.mark.parametrize('train_precision', ['fp32', 'f16x3'])
+def test_main_entry_point_trains_and_saves_checkpoint(dev, tmp_path, train_precision):
     """`python main.py evaluate=False ...`: training loop (loss falls), checkpoint in the reference's naming and
     torch state_dict format (main.py:423-426), which reloads through the prefix lookup (main.py:173-177)."""
     import main as entry
     ck = tmp_path / 'ckpts'
     args = ['model=stofnet', 'evaluate=False', 'epochs=3', 'batch_size=4', 'num_waveforms=24', 'num_samples=400',
-            'th=Null', f'ckpt_dir={ck}', 'run_name=unit-test-7', 'seed=9', 'lr=1e-3']
+            'th=Null', f'ckpt_dir={ck}', 'run_name=unit-test-7', 'seed=9', 'lr=1e-3', f'train_precision={train_precision}']
     es, summary = entry.main(args)
     hist = summary['train_history']
     assert len(hist) == 3 and hist[-1]['train_loss'] < hist[0]['train_loss']
