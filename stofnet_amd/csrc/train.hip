@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_cl_kernel(const WgradParams p)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
     float dbs = 0.f;
+    float4 dbq = make_float4(0.f, 0.f, 0.f, 0.f);
     // A[i = o][k = row parity], B[k][j = c]:  D[o][c] += dY[t][o] * X[t + d - pad][c]
     const float* ap = dys + lh * TROWF + 32 * mi + ln;
     const float* bp = xs + lh * TROWF + 32 * ni + ln;
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_cl_kernel(const WgradParams p)
                     if (o + 2 < p.cout) v.z = src[2];
                 }
             }
+            dbq.x += v.x; dbq.y += v.y; dbq.z += v.z; dbq.w += v.w;        // bias gradient: column sums
             *reinterpret_cast<float4*>(dys + r * TROWF + 4 * q) = v;
         }
         for (int i = tid; i < (WG_ROWS + K - 1) * 16; i += 256) {
@@ -396,10 +398,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_cl_kernel(const WgradParams p)
             for (int d = 0; d < KMAX; ++d)
                 if (d < K) acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(r + d) * TROWF], acc[d], 0, 0, 0);
         }
-        if (blockIdx.z == 0 && tid < 64) {
+    }
+    // bias gradient: thread (row lane tid >> 4, column quad tid & 15) holds the sums of its rows; fold the 16 row lanes
+    if (blockIdx.z == 0) {
+        __syncthreads();
+        *reinterpret_cast<float4*>(xs + (tid >> 4) * 64 + 4 * (tid & 15)) = dbq;
+        __syncthreads();
+        if (tid < 64) {
             float s = 0.f;
-            for (int r = 0; r < WG_ROWS; ++r) s += dys[r * TROWF + tid];
-            dbs += s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += xs[r * 64 + tid];
+            dbs = s;
         }
     }
     // accumulator register v: row (o) = 32mi + (v&3) + 8(v>>2) + 4lh, col (c) = 32ni + ln
@@ -451,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradPar
     // The next tile's rows travel HBM -> registers while the MFMAs of the current tile run.
     constexpr int NDY = WG_ROWS_H * 16 / 256, NX = ((WG_ROWS_H + 8) * 16 + 255) / 256;
     float4 rdy[NDY], rx[NX];
+    float4 dbq = make_float4(0.f, 0.f, 0.f, 0.f);
     auto fetch = [&](int tile) {
         const int n = tile / p.tiles_per_wf;
         const int t0 = (tile - n * p.tiles_per_wf) * WG_ROWS_H;
@@ -494,6 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradPar
         for (int u = 0; u < NDY; ++u) {
             const int i = tid + 256 * u, r = i >> 4, qq = i & 15;
             uint2 hi, lo;
+            dbq.x += rdy[u].x; dbq.y += rdy[u].y; dbq.z += rdy[u].z; dbq.w += rdy[u].w;   // bias gradient: column sums
             split4(rdy[u], hi, lo);
             *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 8 * qq) = hi;
             *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 128 + 8 * qq) = lo;
@@ -525,13 +536,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradPar
                 acc[d] = mma16x3(ah, al, make_uint4(b0.x, b0.y, b1.x, b1.y), make_uint4(m0.x, m0.y, m1.x, m1.y), acc[d]);
             }
         }
-        if (blockIdx.z == 0 && tid < 64) {
+    }
+    // bias gradient: thread (row lane tid >> 4, column quad tid & 15) holds the sums of its rows; fold the 16 row lanes
+    if (blockIdx.z == 0) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(xs);
+        *reinterpret_cast<float4*>(red + (tid >> 4) * 64 + 4 * (tid & 15)) = dbq;
+        __syncthreads();
+        if (tid < 64) {
             float s = 0.f;
-            for (int r = 0; r < WG_ROWS_H; ++r) {
-                const _Float16* row = reinterpret_cast<const _Float16*>(dys + r * HSTRIDE);
-                s += (float)row[tid] + (float)row[64 + tid];
-            }
-            dbs += s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[r * 64 + tid];
+            dbs = s;
         }
     }
     float* part = p.part + (size_t)blockIdx.x * K * p.cout_pad * p.cin_pad;
