@@ -344,9 +344,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
         }
         __syncthreads();
         STAMP_ADD(0);                             // raw load + barrier
-#ifndef STOF_ABLATE_X0
         x0_pass(Xr, F - S, nS, tS);               // sweep layer 0
-#endif
         STAMP_ADD(1);                             // x0 passes
         __syncthreads();
         STAMP_ADD(2);                             // barrier waits
@@ -357,9 +355,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             int nR = nS, tR = tS - layer_lag(j);
             while (tR < 0) { tR += Lp; nR -= 1; }
             if (j == 11) {                        // long skip: seed the destination with x0
-#ifndef STOF_ABLATE_X0
                 x0_pass(Yr, F - S - 33, nR, tR);
-#endif
                 STAMP_ADD(1);
                 __syncthreads();
                 STAMP_ADD(2);
@@ -397,11 +393,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             // then refill w with the fragments of chunk c+2
             auto do_chunk = [&](uint4 (&w)[FRAGS_PER_CHUNK], uint4 (&bcur)[NT][FRAGS_PER_CHUNK],
                                 uint4 (&bnext)[NT][FRAGS_PER_CHUNK], int cc) {
-#ifdef STOF_ABLATE_W
-                const int c2 = 0;              // timing experiment: always the same (cache-hot) fragments
-#else
                 const int c2 = (c + 2 >= BODY_NCHUNK) ? c + 2 - BODY_NCHUNK : c + 2;
-#endif
                 bload(bnext, cc + 1);          // past the layer's last chunk this reads rows nobody uses
                 if constexpr (PREC == STOF_PREC_FP32) {
 #pragma unroll
@@ -661,17 +653,6 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             STAMP_ADD(4);                         // chunk loop (MFMA)
 
             // ---- epilogue of sweep layer j (the destination ring is not read by this layer)
-#ifdef STOF_ABLATE_EPI
-            {   // timing experiment: keep the MFMAs alive, skip the epilogue
-                float ssum = 0.f;
-#pragma unroll
-                for (int k = 0; k < NT; ++k)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) ssum += acc[k][e];
-                if (ssum == 1.2345e33f) p.y[0] = ssum;
-            }
-            if (false)
-#endif
             {
                 bool valid[NT];
                 int slot[NT], tt[NT], nn[NT];
