@@ -75,7 +75,7 @@ def cpu_baseline(sd, r, y_gpu=None, idx_gpu=None, sample_rows=256, reps=3):
     -- as the checker -- the parity of the timed GPU outputs on the same rows (the input of rank 0 is the same seed)."""
     from oracle import pickers_oracle as po
     from oracle import stofnet_oracle as so
-    from oracle import synth
+    from stofnet_amd import synth
     cores = host_cores()
     torch.set_num_threads(cores)
     x = synth.synth_randn(sample_rows, L, seed=3008)
@@ -106,7 +106,7 @@ def cpu_baseline(sd, r, y_gpu=None, idx_gpu=None, sample_rows=256, reps=3):
 def train_bench(args, dev, dist, rank, world):
     """BASELINE.json configs[4]: one training step = forward (activations kept) + Gaussian-mask loss + backward +
     mean all-reduce of the single 2.58 MB gradient bucket (RCCL, N > 1) + AdamW, exact fp32, batch per GPU fixed."""
-    from oracle import synth                      # deterministic inputs/weights only
+    from stofnet_amd import synth                      # deterministic inputs/weights only
     from stofnet_amd import StofNet
     from stofnet_amd.training import StofNetTrainer
     sd = synth.synth_state_dict(R, seed=3008)
@@ -207,7 +207,7 @@ def main():
     if args.mode == 'train':
         return train_bench(args, dev, dist, rank, world)
 
-    from oracle import synth                      # deterministic inputs/weights only (not the oracle math)
+    from stofnet_amd import synth                      # deterministic inputs/weights only (not the oracle math)
     from stofnet_amd import StofNet, _lib
     from stofnet_amd.mask2samples import onset_indices
 

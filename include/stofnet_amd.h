@@ -10,7 +10,9 @@
  *   - plain pointers and sizes only; device pointers are raw HIP device
  *     addresses, `stream` is a hipStream_t passed as void*.
  *   - ownership: the caller owns every buffer including workspaces; the library
- *     allocates nothing per call and keeps no mutable global state.
+ *     allocates nothing per call and keeps no data between calls (its only state is a
+ *     per-device "LDS limit already raised" bit per kernel, set with atomics), so one host
+ *     thread per GPU -- or several GPUs from one process -- may call concurrently.
  *   - all device work is enqueued asynchronously on `stream`; no hidden syncs.
  *   - every function returns a stof_status (0 = ok); nothing throws or aborts
  *     across the ABI.  stof_status_string() gives a static message.

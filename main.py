@@ -35,7 +35,7 @@ def load_frames(cfg):
         arr = np.load(cfg.input_file).astype(np.float32)
         arr = arr[:, None, :] if arr.ndim == 2 else arr
         return arr / np.abs(arr).max(axis=-1, keepdims=True), None     # NormalizeVol (utils/transforms.py:13)
-    from oracle.synth import synth_echo          # deterministic demo inputs only
+    from stofnet_amd.synth import synth_echo          # deterministic demo inputs only
     x, onsets = synth_echo(int(cfg.num_waveforms), int(cfg.num_samples), seed=int(cfg.seed), return_onsets=True)
     return x, onsets.astype(np.float32)[:, None]
 

@@ -30,7 +30,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'stofnet_amd.h')]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp', '.h'))] + [os.path.join(HERE, '..', 'include', 'stofnet_amd.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -45,7 +45,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
-            continue
+            raise RuntimeError(f'listed source {path} is missing: refusing to link a library without its symbols')
         obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
         cmd = [hipcc, '-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-x', 'hip', '-c', path, '-o', obj]
         if verbose:

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "stof_common.h"
+#include "stof_hip_util.h"
 
 // expand_conv 512->64 k5 on the pooled grid + lrelu runs on the channel-last MFMA conv of train.hip in stream mode (the P
 // pooled columns of every waveform followed by 2 zero gap rows form one long row sequence, so the 128-row tiles are full).
@@ -961,21 +962,12 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
     const float* ebias = base + off;
 
     using Lds = BodyLds<BODY_S, BODY_RING, BODY_RAWRING>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds::BYTES) != hipSuccess)
-            return STOF_ERR_HIP;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sgb_contract_pool_kernel<PREC, SGB_NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sgb_lds_bytes()) != hipSuccess)
-            return STOF_ERR_HIP;
-        attr_done = true;
-    }
-    int dev = 0, ncu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
-    }
+    static LdsLimitOnce body_lds, sgb_lds;                 // one per template instantiation (PREC)
+    if (int st = body_lds.ensure(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>),
+                                 (int)Lds::BYTES)) return st;
+    if (int st = sgb_lds.ensure(reinterpret_cast<const void*>(&sgb_contract_pool_kernel<PREC, SGB_NW>), (int)sgb_lds_bytes()))
+        return st;
+    const int ncu = device_cu_count();
 
     for (int64_t b0 = 0; b0 < N; b0 += SUB_BATCH) {
         const int64_t nb = (N - b0) < SUB_BATCH ? (N - b0) : SUB_BATCH;

@@ -12,6 +12,7 @@
 // through a second LDS buffer.
 #include <hip/hip_runtime.h>
 #include "stof_common.h"
+#include "stof_hip_util.h"
 
 namespace {
 
@@ -286,14 +287,8 @@ extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, fl
     using Kern = void (*)(const float*, const float2*, const float*, const FftPlan, long long, float*, float*, float*);
     const Kern kern = tw_lds ? (pair ? &hilbert_kernel<true, true> : &hilbert_kernel<true, false>)
                              : (pair ? &hilbert_kernel<false, true> : &hilbert_kernel<false, false>);
-    static bool attr_done[4] = {false, false, false, false};
-    const int ki = (tw_lds ? 2 : 0) + (pair ? 1 : 0);
-    if (!attr_done[ki]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
-            hipSuccess)
-            return STOF_ERR_HIP;
-        attr_done[ki] = true;
-    }
+    static stof::LdsLimitOnce lds_once[4];
+    if (int st = lds_once[(tw_lds ? 2 : 0) + (pair ? 1 : 0)].ensure(reinterpret_cast<const void*>(kern), LDS_BYTES)) return st;
     float2* tw = static_cast<float2*>(workspace);
     float* hf = reinterpret_cast<float*>(tw + n);
     hipLaunchKernelGGL(tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, hf, plan);

@@ -14,6 +14,7 @@
 // out = (acc (+ residual)) * act'(saved), where act' is read off the sign of the saved activation.
 #include <hip/hip_runtime.h>
 #include "stof_common.h"
+#include "stof_hip_util.h"
 
 using namespace stof;
 
@@ -1027,12 +1028,8 @@ extern "C" int stof_train_loss(const float* pred, const int64_t* gt_idx, int64_t
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(tmax, 0, sizeof(float), s) != hipSuccess || hipMemsetAsync(loss, 0, sizeof(double), s) != hipSuccess)
         return STOF_ERR_HIP;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_target_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess) return STOF_ERR_HIP;
-        attr_done = true;
-    }
+    static stof::LdsLimitOnce loss_lds;
+    if (int st = loss_lds.ensure(reinterpret_cast<const void*>(&loss_target_kernel), 160 * 1024)) return st;
     hipLaunchKernelGGL(loss_target_kernel, dim3((unsigned)N), dim3(256), (size_t)M * sizeof(float), s,
                        reinterpret_cast<const long long*>(gt_idx), (int)G, taps7, target, (int)N, (int)M, tmax);
     const unsigned lblocks = blocks_for(N * M) < 2048u ? blocks_for(N * M) : 2048u;   // one double atomic per block

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, REF)
 sys.dont_write_bytecode = True
 
-from oracle import synth  # noqa: E402  (our own deterministic input generator)
+from stofnet_amd import synth  # noqa: E402  (our own deterministic input generator)
 
 from models.stofnet import StofNet  # noqa: E402  (reference)
 from models.gradpeak import GradPeak, toa_detect, grad_peak_detect, gaussian_kernel_1d, gaussian_filter_1d  # noqa: E402

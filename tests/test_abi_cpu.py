@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, load_weights
-from oracle import synth
+from stofnet_amd import synth
 from stofnet_amd import _lib
 from stofnet_amd import build as sbuild
 

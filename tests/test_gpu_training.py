@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import synth
+from stofnet_amd import synth
 from oracle import train_oracle as to
 
 pytestmark = pytest.mark.gpu

@@ -22,8 +22,9 @@ def test_config_load_merge_types():
         cm.from_cli(['novalue'])
 
 
-def test_toa_rmse_matches_reference_golden():
+def test_toa_rmse_refuses_cpu_tensors():
+    """No CPU fallback in the product: the device metric raises for host tensors (the CPU restatement is
+    oracle/pickers_oracle.py:toa_rmse, pinned in test_oracle_golden.py)."""
     g = golden('f7_metrics')
-    for tol in [1, 4]:
-        got = toa_rmse(torch.from_numpy(g['gt']), torch.from_numpy(g['es']), tol=tol).numpy()
-        assert np.allclose(got, g[f'rmse_tol{tol}'], rtol=1e-6, atol=0, equal_nan=True)
+    with pytest.raises(RuntimeError, match='ROCm device only'):
+        toa_rmse(torch.from_numpy(g['gt']), torch.from_numpy(g['es']), tol=1)

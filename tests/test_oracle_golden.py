@@ -10,7 +10,7 @@ import torch
 from conftest import GOLDEN, golden, load_weights
 from oracle import pickers_oracle as po
 from oracle import stofnet_oracle as so
-from oracle import synth
+from stofnet_amd import synth
 
 MANIFEST = json.load(open(os.path.join(GOLDEN, 'manifest.json')))
 

@@ -6,7 +6,7 @@ import torch
 
 from conftest import load_weights
 from oracle import stofnet_oracle as so
-from oracle import synth
+from stofnet_amd import synth
 from oracle.sweep_emulator import sweep_forward
 
 

@@ -3,7 +3,7 @@ Prints one JSON line per kernel: algorithmic GB/s = bytes the op must move / tim
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import synth
+from stofnet_amd import synth
 from stofnet_amd import SampleShuffle1D, mask2coords
 from stofnet_amd.hilbert import hilbert_envelope
 from stofnet_amd.mask2samples import onset_indices

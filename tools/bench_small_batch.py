@@ -3,7 +3,7 @@
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import synth
+from stofnet_amd import synth
 from stofnet_amd import StofNet
 dev = torch.device('cuda:0')
 r, L = 10, 2000

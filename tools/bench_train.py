@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import synth  # input generator only
+from stofnet_amd import synth  # input generator only
 from stofnet_amd import StofNet
 from stofnet_amd.training import StofNetTrainer
 

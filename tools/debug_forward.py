@@ -2,7 +2,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import stofnet_oracle as so, synth
+from oracle import stofnet_oracle as so
+from stofnet_amd import synth
 from stofnet_amd import StofNet
 
 dev = torch.device('cuda:0')

@@ -3,7 +3,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import synth, train_oracle as to
+from stofnet_amd import synth
+from oracle import train_oracle as to
 from stofnet_amd import StofNet
 from stofnet_amd.training import StofNetTrainer
 dev = torch.device('cuda:0')

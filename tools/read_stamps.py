@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import synth
+from stofnet_amd import synth
 from stofnet_amd import StofNet
 dev = torch.device('cuda:0')
 prec = sys.argv[1] if len(sys.argv) > 1 else 'f16x3'
