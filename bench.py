@@ -1,38 +1,104 @@
 #!/usr/bin/env python3
-"""bench.py -- StofNet inference throughput on MI355X (BASELINE.json metric).
+"""bench.py -- StofNet hot-path throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W] [--config C2|C3|C4|C5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path (StofNet.forward: SemiGlobalBlock kernels + fused body
-sweep incl. the SampleShuffle1D store) over one resident batch of synthetic waveforms:
-configuration C2 of BASELINE.json, fp32 [4096,1,2000] -> [4096,1,20000] at upsample_factor
-10 with seeded-random weights (all shipped checkpoints have r=4).
-Rows are independent, so N GPUs each own a [4096,1,2000] batch (weak scaling) and the forward
-has no collective; the optional gather of onset indices over RCCL is timed separately.
+One "step" = one pass of the hot path over one resident batch of synthetic waveforms per GPU:
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
-dominant kernel (body sweep, MFMA-bound, timed with HIP events on its launch stream) and
-`cpu_baseline` (the CPU oracle = PyTorch-CPU restatement, timed on this box's host cores).
+  C2 (default)  StofNet.forward, fp32 [4096,1,2000] -> [4096,1,20000], upsample_factor 10, seeded weights
+                (BASELINE.json configs[1]: the configuration the metric is quoted on)
+  C3            the same at upsample_factor 20 -> [4096,1,40000] (configs[2], stresses the SampleShuffle1D store)
+  C4            PALA shape (configs[3]): 131,072 rows of 1536 samples per GPU in 8192-row chunks, upsample_factor 4,
+                checkpoint graceful-snow, forward + mask2coords picker in threshold mode th = 0.015
+                (bash_scripts/array_pala_params.txt:1), ragged onset indices gathered over RCCL afterwards
+  C5            training step (configs[4]): forward + Gaussian-mask loss + backward + gradient all-reduce + AdamW
+
+Rows are independent, so N GPUs each own their own batch (weak scaling) and the forward has no collective; the optional
+gather of onset indices (one MAX all-reduce of Kmax + one all_gather of int32 indices) is timed separately.
+
+Launch: with --gpus N > 1 and no RANK in the environment this process only spawns N children (one per GPU, RCCL
+rendezvous on 127.0.0.1) and relays rank 0's line -- it never touches the GPU itself; under torch.distributed.run the
+ranks come from the environment and --gpus must agree with WORLD_SIZE.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel (body sweep,
+MFMA-bound, timed with HIP events on its launch stream inside the timed region) and `cpu_baseline` (the CPU oracle =
+PyTorch-CPU restatement, timed on this box's host cores, N = 1 only).
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_ROWS, L, R = 4096, 2000, 10
-PREHEAT_STEPS = 25      # untimed forward passes before the W warm-up steps (≈0.5 s of GPU time)
-PEAK_TFLOPS = {'fp32': 157.3, 'f16x3': 2500.0 / 3.0}   # MI355X_MICROARCH.md: fp32 MFMA 157.3; f16 2.5 PF / 3 passes
+L_CHIRP = 2000
+PREHEAT_SECONDS = 1.5      # untimed passes before the W warm-up steps so the clocks / power state have settled
+PEAK_TFLOPS = {'fp32': 157.3, 'f16x3': 2500.0 / 3.0, 'auto': 2500.0 / 3.0}   # MI355X_MICROARCH.md: fp32 MFMA 157.3; f16 2.5 PF / 3 passes
+DTYPE_TEXT = {'fp32': 'f32', 'f16x3': 'f32 via split-fp16 x3 MFMA operands (hi+lo, fp32 accumulate)',
+              'auto': 'f32 via split-fp16 x3 MFMA operands (hi+lo, fp32 accumulate), device-side exact-f32 re-run on fp16 range overflow'}
+C4_ROWS, C4_CHUNK, C4_L, C4_R, C4_TH = 131072, 8192, 1536, 4, 0.015
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='C2', choices=['C2', 'C3', 'C4', 'C5'])
+    ap.add_argument('--precision', default=os.environ.get('STOF_PRECISION', 'auto'), choices=['auto', 'fp32', 'f16x3'])
+    ap.add_argument('--no-fp32-extra', action='store_true', help='skip the secondary exact-fp32 measurement')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'], help="'train' = --config C5")
+    ap.add_argument('--train-batch', type=int, default=256, help='waveforms per GPU per training step')
+    ap.add_argument('--train-precision', default='fp32', choices=['fp32', 'f16x3'],
+                    help='arithmetic of the convolutions of the training step')
+    ap.add_argument('--rows', type=int, default=0, help='override the rows per GPU of the chosen config (smoke runs)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='rehearse the launcher and the distributed plumbing on the CPU (gloo, no kernels): tests only')
+    args = ap.parse_args(argv)
+    if args.mode == 'train':
+        args.config = 'C5'
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    return args
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: python bench.py --gpus N  ->  N children, one per GPU.  Standard library only; the parent never
+# imports torch or touches the GPU, and children are started with subprocess (never exec of a GPU process).
+# ------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_children(args, argv):
+    port = os.environ.get('MASTER_PORT') or str(free_port())
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write(f'bench.py: ranks failed (rank, exit code): {bad}\n')
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
 def body_flops(n, l, r):
     """conv1 + conv2..12 + conv_last, the work of the body-sweep kernel."""
     return 2.0 * n * l * (576 + 11 * 28672 + 192 * r)
@@ -70,98 +136,188 @@ def host_cores():
     return min(cores, 64)
 
 
-def cpu_baseline(sd, r, y_gpu=None, idx_gpu=None, sample_rows=256, reps=3):
-    """The oracle (oracle/stofnet_oracle.py, PyTorch CPU fp32) on a bounded sample: its speed on the host cores, and
-    -- as the checker -- the parity of the timed GPU outputs on the same rows (the input of rank 0 is the same seed)."""
+def cpu_baseline(sd, r, L, x_np, y_gpu=None, idx_gpu=None, threshold=None, reps=3):
+    """The oracle (oracle/stofnet_oracle.py, PyTorch CPU fp32; oracle/pickers_oracle.py) on a bounded sample `x_np`
+    [rows,1,L]: its speed on the host cores, the batch-1 figure of BASELINE config C1 (wall and the reference's
+    time.process_time() methodology, main.py:313-315), and -- as the checker -- the parity of the timed GPU outputs."""
+    import numpy as np
+    import torch
     from oracle import pickers_oracle as po
     from oracle import stofnet_oracle as so
-    from stofnet_amd import synth
     cores = host_cores()
     torch.set_num_threads(cores)
-    x = synth.synth_randn(sample_rows, L, seed=3008)
+    rows = x_np.shape[0]
     with torch.no_grad():
-        so.stofnet_forward(sd, x[:16], r)          # warm-up
+        so.stofnet_forward(sd, x_np[:16], r)          # warm-up
         t0 = time.perf_counter()
         for _ in range(reps):
-            y_ref = so.stofnet_forward(sd, x, r)
+            y_ref = so.stofnet_forward(sd, x_np, r)
         dt = (time.perf_counter() - t0) / reps
-    out = {'value': round(sample_rows / dt, 2), 'unit': 'waveforms/s', 'cores': cores, 'kind': 'port',
-           'sample': f'[{sample_rows},1,{L}] fp32, upsample_factor={r}, PyTorch-CPU oracle, '
-                     f'{reps} reps after warm-up, torch {torch.__version__}'}
+        so.stofnet_forward(sd, x_np[:1], r)
+        t0, p0 = time.perf_counter(), time.process_time()
+        for _ in range(5):
+            so.stofnet_forward(sd, x_np[:1], r)
+        w1, p1 = (time.perf_counter() - t0) / 5, (time.process_time() - p0) / 5
+    out = {'value': round(rows / dt, 2), 'unit': 'waveforms/s', 'cores': cores, 'kind': 'port',
+           'sample': f'[{rows},1,{L}] fp32, upsample_factor={r}, PyTorch-CPU oracle forward, '
+                     f'{reps} reps after warm-up, torch {torch.__version__}',
+           'batch1': {'waveforms_per_s': round(1.0 / w1, 2), 'wall_ms': round(w1 * 1e3, 2),
+                      'process_time_ms': round(p1 * 1e3, 2),
+                      'note': 'C1 shape [1,1,L]; process_time = CPU time over all threads, the reference\'s main.py:313-315 method'}}
     if y_gpu is not None:
         y_ref = y_ref.numpy()
-        ref_idx = po.maxima_positions(y_ref, 20, None)       # int64 [K, 2] (row, index), arg-max mode
-        first = np.full(sample_rows, -1, np.int64)
-        for row, t in ref_idx[::-1]:
-            first[row] = t
-        got = (idx_gpu[:sample_rows, 0].cpu().numpy().astype(np.int64) if idx_gpu.shape[1] > 0
-               else np.full(sample_rows, -1, np.int64))
+        prow = min(rows, 64 if threshold else rows)
+        ref = po.mask2coords(y_ref[:prow], 20, threshold, 1)                     # [prow, K] (zero padded) in output samples
+        got = np.zeros_like(ref) if ref.ndim == 2 else ref
+        if ref.ndim == 2:
+            k = min(ref.shape[1], idx_gpu.shape[1])
+            g = idx_gpu[:prow, :k].cpu().numpy().astype(np.float32)
+            got[:, :k] = g
         out['parity_on_sample'] = {
-            'onset_index_mae': float(np.abs(got - first).mean()),
-            'onset_index_mismatches': int((got != first).sum()),
-            'max_rel_err_maps': float(np.abs(y_gpu[:sample_rows].cpu().numpy() - y_ref).max() / np.abs(y_ref).max())}
+            'picker': 'arg-max' if not threshold else f'threshold {threshold}', 'rows': int(prow),
+            'onset_index_mae': float(np.abs(got - ref).mean()) if ref.ndim == 2 else 0.0,
+            'onset_index_mismatches': int((got != ref).sum()) if ref.ndim == 2 else 0,
+            'max_rel_err_maps': float(np.abs(y_gpu[:rows].cpu().numpy() - y_ref).max() / np.abs(y_ref).max())}
     return out
 
 
-def train_bench(args, dev, dist, rank, world):
+class Dist:
+    """torch.distributed plumbing shared by every config: barrier, MAX of the timed interval."""
+
+    def __init__(self, args, backend):
+        import torch
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        if self.world != args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: launch with '
+                             f'`python bench.py --gpus N` or torch.distributed.run --nproc-per-node N')
+        self.dist = None
+        self.dev = torch.device('cpu') if backend == 'gloo' else torch.device('cuda', self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29500')
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            if backend == 'nccl':
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
+            self.dist = dist
+        if backend == 'nccl':
+            torch.cuda.set_device(self.dev)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def sync(self):
+        import torch
+        if self.dev.type == 'cuda':
+            torch.cuda.synchronize()
+
+    def timed(self, fn, steps):
+        """EXACTLY `steps` calls of fn bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        import torch
+        self.sync()
+        self.barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            fn(s)
+        self.sync()
+        self.barrier()
+        self.sync()
+        dt = time.perf_counter() - t0
+        if self.dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def base_line(args, d, metric, value, dt, dtype, workload, config_extra):
+    return {'metric': metric, 'value': round(value, 1), 'unit': 'waveforms/s', 'n_gpus': d.world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+            'config': dict({'workload': workload}, **config_extra)}
+
+
+def dry_run(args):
+    """Launcher / process-group rehearsal on the CPU (gloo): the same barrier + max-over-ranks timing and the same
+    ragged index gather as the real configs, with a no-op step.  Used by tests/test_bench_launcher.py."""
+    import torch
+    from stofnet_amd.sharding import gather_onsets
+    d = Dist(args, 'gloo')
+    rows = args.rows or 8
+    dt = d.timed(lambda s: time.sleep(0.001), args.steps)
+    counts = torch.full((rows,), 1 + d.rank, dtype=torch.int32)
+    idx = torch.arange(rows * (1 + d.rank), dtype=torch.int32).reshape(rows, 1 + d.rank) + 1000 * d.rank
+    gather_ms = None
+    if d.dist is not None:
+        t1 = time.perf_counter()
+        counts_all, idx_all = gather_onsets(counts, idx)
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        assert counts_all.shape[0] == rows * d.world and idx_all.shape[1] == d.world
+    if d.rank == 0:
+        out = base_line(args, d, 'dry run (no kernels)', d.world * rows * args.steps / dt, dt, 'none',
+                        'launcher rehearsal on CPU/gloo', {'rows_per_gpu': rows})
+        out['dry_run'] = True
+        out['extras'] = {'index_gather_ms': None if gather_ms is None else round(gather_ms, 3)}
+        print(json.dumps(out), flush=True)
+    d.finish()
+
+
+def train_bench(args):
     """BASELINE.json configs[4]: one training step = forward (activations kept) + Gaussian-mask loss + backward +
-    mean all-reduce of the single 2.58 MB gradient bucket (RCCL, N > 1) + AdamW, exact fp32, batch per GPU fixed."""
-    from stofnet_amd import synth                      # deterministic inputs/weights only
-    from stofnet_amd import StofNet
+    mean all-reduce of the single 2.58 MB gradient bucket (RCCL, N > 1) + AdamW, batch per GPU fixed."""
+    import numpy as np
+    import torch
+    from stofnet_amd import StofNet, synth
     from stofnet_amd.training import StofNetTrainer
+    d = Dist(args, 'nccl')
+    R, L = 10, L_CHIRP
     sd = synth.synth_state_dict(R, seed=3008)
     model = StofNet(upsample_factor=R)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
-    tr = StofNetTrainer(model.to(dev), precision=args.train_precision)
-    nb = args.train_batch
-    x = torch.from_numpy(synth.synth_echo(nb, L, seed=3008 + rank)).to(dev)
-    rng = np.random.default_rng(rank)
-    gt = torch.from_numpy(np.sort(rng.integers(1, L * R, size=(nb, 1, 2)), -1)).to(dev)
+    tr = StofNetTrainer(model.to(d.dev), precision=args.train_precision)
+    nb = args.rows or args.train_batch
+    x = torch.from_numpy(synth.synth_echo(nb, L, seed=3008 + d.rank)).to(d.dev)
+    rng = np.random.default_rng(d.rank)
+    gt = torch.from_numpy(np.sort(rng.integers(1, L * R, size=(nb, 1, 2)), -1)).to(d.dev)
+    last = {}
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def step(_s):
+        last['loss'], _ = tr.train_step(x, gt)
 
-    for _ in range(args.warmup):
-        loss, _ = tr.train_step(x, gt)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = tr.train_step(x, gt)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    if rank == 0:
+    for s in range(args.warmup):
+        step(s)
+    dt = d.timed(step, args.steps)
+    if d.rank == 0:
         flops = 3.0 * total_flops(nb, L, R)        # forward + data-gradient + weight-gradient
         achieved = flops * args.steps / dt / 1e12
-        out = {
-            'metric': 'RF waveforms/sec StofNet training step (fwd+bwd+AdamW) rf_scale=10',
-            'value': round(world * nb * args.steps / dt, 1), 'unit': 'waveforms/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.train_precision == 'fp32' else 'f32 via split-fp16 x3 MFMA operands (hi+lo, fp32 accumulate) in fwd, dgrad and wgrad convolutions',
-            'data': 'synthetic',
-            'config': {'workload': f'C5 training step [{nb},1,{L}] -> [{nb},1,{L * R}] per GPU, Gaussian-mask loss, AdamW, '
-                                   f'upsample_factor={R}', 'rows_per_gpu': nb, 'L': L, 'upsample_factor': R,
-                       'parallelism': f'ddp{world}: one flat 2.58 MB gradient all-reduce per step'},
-            'roofline': {'bound': 'mfma', 'kernel': 'whole step (conv_cl_kernel + conv_wgrad_cl_kernel, fp32 MFMA)',
-                         'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS['fp32'], 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_TFLOPS['fp32'], 4), 'traffic': None},
-            'final_loss': float(loss),
-        }
-        if world == 1 and not args.no_cpu_baseline:
+        peak = PEAK_TFLOPS[args.train_precision]
+        out = base_line(args, d, 'RF waveforms/sec StofNet training step (fwd+bwd+AdamW) rf_scale=10',
+                        d.world * nb * args.steps / dt, dt, DTYPE_TEXT[args.train_precision],
+                        f'C5 training step [{nb},1,{L}] -> [{nb},1,{L * R}] per GPU, Gaussian-mask loss, AdamW, upsample_factor={R}',
+                        {'rows_per_gpu': nb, 'L': L, 'upsample_factor': R, 'precision': args.train_precision,
+                         'parallelism': f'ddp{d.world}: one flat 2.58 MB gradient all-reduce per step'})
+        out['roofline'] = {'bound': 'mfma', 'kernel': f'whole step (conv_cl_kernel + conv_wgrad kernels, {args.train_precision} MFMA)',
+                           'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                           'frac': round(achieved / peak, 4), 'traffic': None}
+        out['final_loss'] = float(last['loss'])
+        if d.world == 1 and not args.no_cpu_baseline:
             # the oracle's training step (torch autograd on the host cores), bounded sample
             from oracle import train_oracle
             cores = host_cores()
             torch.set_num_threads(cores)
-            rows = 32
+            rows = min(32, nb)
             xs, gts = x[:rows].cpu().numpy(), gt[:rows].cpu().numpy()
             train_oracle.loss_and_grads(sd, xs[:4], gts[:4], R, 80, dtype=torch.float32)
             t1 = time.perf_counter()
@@ -170,52 +326,56 @@ def train_bench(args, dev, dist, rank, world):
             out['cpu_baseline'] = {'value': round(rows / cdt, 2), 'unit': 'waveforms/s', 'cores': cores, 'kind': 'port',
                                    'sample': f'1 fwd+bwd of {rows} waveforms (oracle, torch autograd fp32), optimizer step excluded'}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    d.finish()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--precision', default=os.environ.get('STOF_PRECISION', 'f16x3'), choices=['fp32', 'f16x3'])
-    ap.add_argument('--no-fp32-extra', action='store_true', help='skip the secondary exact-fp32 measurement')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
-                    help="'train' times BASELINE.json configs[4] (fwd+bwd+AdamW, DDP gradient all-reduce) instead")
-    ap.add_argument('--train-batch', type=int, default=256, help='waveforms per GPU per training step')
-    ap.add_argument('--train-precision', default='fp32', choices=['fp32', 'f16x3'],
-                    help='arithmetic of the forward / data-gradient convolutions of the training step')
-    args = ap.parse_args()
+def load_fixture_weights(key):
+    """Checkpoint tensors committed as data under tests/golden (the reference's .pth cannot travel)."""
+    import numpy as np
+    d = np.load(os.path.join(ROOT, 'tests', 'golden', f'weights_{key}.npz'))
+    return {k: d[k] for k in d.files}
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
 
-    if args.mode == 'train':
-        return train_bench(args, dev, dist, rank, world)
-
-    from stofnet_amd import synth                      # deterministic inputs/weights only (not the oracle math)
-    from stofnet_amd import StofNet, _lib
-    from stofnet_amd.mask2samples import onset_indices
-
-    sd = synth.synth_state_dict(R, seed=3008)
+def infer_bench(args):
+    import ctypes
+    import numpy as np
+    import torch
+    from stofnet_amd import StofNet, _lib, synth
+    from stofnet_amd.mask2samples import onset_indices, pick_async
+    from stofnet_amd.sharding import gather_onsets
+    d = Dist(args, 'nccl')
+    dev = d.dev
+    cfg = args.config
+    if cfg == 'C4':
+        R, L, chunk = C4_R, C4_L, C4_CHUNK
+        rows = args.rows or C4_ROWS
+        chunk = min(chunk, rows)
+        rows = rows // chunk * chunk
+        sd = load_fixture_weights('graceful-snow')
+        th = C4_TH
+        # 8192 host-generated echoes (seeded, NormalizeVol), replicated on the device with fresh seeded noise per chunk
+        base = torch.from_numpy(synth.synth_echo(chunk, L, seed=3008 + d.rank)).to(dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(3008 + d.rank)
+        x = torch.empty((rows, 1, L), dtype=torch.float32, device=dev)
+        for c in range(rows // chunk):
+            v = base if c == 0 else base + 0.01 * torch.randn(base.shape, generator=g, device=dev)
+            x[c * chunk:(c + 1) * chunk] = v / v.abs().amax(dim=-1, keepdim=True)
+        workload = (f'C4 PALA shape: {rows} rows x {L} samples per GPU in {chunk}-row chunks, StofNet.forward -> '
+                    f'[{chunk},1,{L * R}] + mask2coords picker (threshold {th}, window 20), upsample_factor={R}, '
+                    f'checkpoint graceful-snow')
+    else:
+        R = 20 if cfg == 'C3' else 10
+        L, rows = L_CHIRP, args.rows or 4096
+        chunk, th = rows, None
+        sd = synth.synth_state_dict(R, seed=3008)
+        x = torch.from_numpy(synth.synth_randn(rows, L, seed=3008 + d.rank)).to(dev)   # resident before timing
+        workload = (f'{cfg} StofNet.forward [{rows},1,{L}] -> [{rows},1,{L * R}] per GPU, upsample_factor={R}, '
+                    f'SemiGlobalBlock on, seeded-random weights (seed 3008)')
+    nchunk = rows // chunk
     model = StofNet(upsample_factor=R, precision=args.precision)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
-    x = torch.from_numpy(synth.synth_randn(N_ROWS, L, seed=3008 + rank)).to(dev)   # resident before timing
 
     lib = _lib.lib()
     nev = 4
@@ -225,30 +385,38 @@ def main():
         _lib.check(lib.stof_events_create(nev, arr))
         ev_sets.append(arr)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    PICK_CAP = 256          # detections kept per row (threshold mode on noisy rows finds tens); checked after the timed region
+    res = {}
+    if cfg == 'C4':
+        counts_all = torch.zeros((rows,), dtype=torch.int32, device=dev)
+        idx_all = torch.zeros((rows, PICK_CAP), dtype=torch.int32, device=dev)
 
-    for _ in range(PREHEAT_STEPS):                 # untimed: lets the clocks/power state settle whatever W is
-        y = model(x)
-    for _ in range(args.warmup):
-        y = model(x)
-    torch.cuda.synchronize()
-    barrier()
+    def step(s, events=True):
+        for c in range(nchunk):
+            xs = x if nchunk == 1 else x[c * chunk:(c + 1) * chunk]
+            y = model(xs, _events=ev_sets[s] if (events and c == 0) else None)
+            if cfg == 'C4':                   # the C4 hot path includes the picker; no host sync inside the step
+                pick_async(y, 20, th, counts=counts_all[c * chunk:(c + 1) * chunk], idx=idx_all[c * chunk:(c + 1) * chunk])
+        res['y'] = y
+
+    step(0, events=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        y = model(x, _events=ev_sets[s])
+    step(0, events=False)
     torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    one = max(time.perf_counter() - t0, 1e-4)
+    preheat = max(1, int(PREHEAT_SECONDS / one))
+    for _ in range(preheat):                        # untimed: lets the clocks/power state settle whatever W is
+        step(0, events=False)
+    for _ in range(args.warmup):
+        step(0, events=False)
+    dt = d.timed(step, args.steps)
+    y = res['y']
+    fell_back = model.fell_back_to_fp32() if args.precision == 'auto' else False
+    if args.precision == 'f16x3':
+        model.raise_if_overflow()
 
-    # per-kernel durations from the HIP events recorded inside the timed region
+    # per-kernel durations from the HIP events recorded inside the timed region (first chunk of every step)
     kern = np.zeros((args.steps, 3))
     ms = ctypes.c_float()
     for s, arr in enumerate(ev_sets):
@@ -259,26 +427,50 @@ def main():
     k_ms = kern.mean(0)
 
     # extras outside the timed region: picker and optional RCCL gather of the onset indices
-    counts, idx = onset_indices(y, 20, None)          # warm-up: first use loads the picker's code object
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        counts, idx = onset_indices(y, 20, None)      # includes the Kmax host sync the reference has too
-    torch.cuda.synchronize()
-    pick_ms = (time.perf_counter() - t1) * 1e3 / 5
-    gather_ms = None
-    if dist is not None:
-        onset = (idx[:, 0] if idx.shape[1] > 0 else torch.zeros(idx.shape[0], dtype=idx.dtype, device=dev)).contiguous()
-        outs = [torch.empty_like(onset) for _ in range(world)]
+    extras = {}
+    if cfg == 'C4':
+        kmax = int(counts_all.max())
+        if kmax > PICK_CAP:
+            raise SystemExit(f'bench.py: a row produced {kmax} detections > cap {PICK_CAP}')
+        counts = counts_all
+        ar = torch.arange(max(kmax, 1), device=dev)[None, :]
+        idx = torch.where(ar < counts[:, None], idx_all[:, :max(kmax, 1)], torch.zeros((), dtype=torch.int32, device=dev)).contiguous()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        dist.all_gather(outs, onset)
+        for c in range(nchunk):
+            model(x[c * chunk:(c + 1) * chunk])
         torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - t1) * 1e3
+        fwd_only = time.perf_counter() - t1
+        extras['forward_only_ms_per_step'] = round(fwd_only * 1e3, 3)
+        extras['picker_threshold_ms_per_step'] = round(dt / args.steps * 1e3 - fwd_only * 1e3, 3)
+        extras['detections_per_row_mean'] = round(float(counts.float().mean()), 3)
+        extras['kmax'] = kmax
+    else:
+        counts, idx = onset_indices(y, 20, None)          # warm-up: first use loads the picker's code object
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            counts, idx = onset_indices(y, 20, None)      # includes the Kmax host sync the reference has too
+        torch.cuda.synchronize()
+        pick_ms = (time.perf_counter() - t1) * 1e3 / 5
+        ar = torch.arange(idx.shape[1], device=dev)[None, :]
+        idx = torch.where(ar < counts[:, None], idx, torch.zeros((), dtype=torch.int32, device=dev)).contiguous()
+        extras['picker_argmax_ms'] = round(pick_ms, 3)
+        extras['waveforms_per_s_forward_plus_picker'] = round(d.world * rows / (dt / args.steps + pick_ms * 1e-3), 1)
+    extras['index_gather_ms'] = None
+    if d.dist is not None:
+        gather_onsets(counts, idx)                       # warm-up (communicator set-up)
+        torch.cuda.synchronize()
+        d.barrier()
+        t1 = time.perf_counter()
+        c_all, i_all = gather_onsets(counts, idx)
+        torch.cuda.synchronize()
+        extras['index_gather_ms'] = round((time.perf_counter() - t1) * 1e3, 3)
+        extras['gathered_rows'] = int(c_all.shape[0])
+        extras['gathered_kmax'] = int(i_all.shape[1])
 
     # secondary measurement: the exact-fp32 parity-baseline mode, same workload (outside the timed region)
-    fp32_extra = None
-    if args.precision != 'fp32' and not args.no_fp32_extra:
+    if args.precision != 'fp32' and not args.no_fp32_extra and cfg != 'C4':
         m32 = StofNet(upsample_factor=R, precision='fp32')
         m32.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
         m32 = m32.to(dev).eval()
@@ -290,52 +482,61 @@ def main():
         torch.cuda.synchronize()
         dt32 = (time.perf_counter() - t1) / 3
         c32, i32 = onset_indices(y32, 20, None)
-        fp32_extra = {'waveforms_per_s_per_gpu': round(N_ROWS / dt32, 1), 'ms_per_step': round(dt32 * 1e3, 3),
-                      'max_rel_diff_vs_timed_mode': float((y32 - y).abs().max() / y32.abs().max()),
-                      'onset_index_mismatches_vs_timed_mode': int((i32[:, :1] != idx[:, :1]).sum())}
+        extras['fp32_exact_mode'] = {'waveforms_per_s_per_gpu': round(rows / dt32, 1), 'ms_per_step': round(dt32 * 1e3, 3),
+                                     'max_rel_diff_vs_timed_mode': float((y32 - y).abs().max() / y32.abs().max()),
+                                     'onset_index_mismatches_vs_timed_mode': int((i32[:, :1] != idx[:, :1]).sum())}
         del m32, y32
+    extras['auto_mode_fp32_rerun_taken'] = bool(fell_back)
 
-    if rank == 0:
-        value = world * N_ROWS * args.steps / dt
+    if d.rank == 0:
+        launch_rows = min(chunk, 4096)              # stof_forward sweeps sub-batches of <= 4096 rows per launch
         body_s = k_ms[2] * 1e-3
-        achieved = body_flops(N_ROWS, L, R) / body_s / 1e12
+        achieved = body_flops(launch_rows, L, R) / body_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and cfg == 'C2':
             try:
                 traffic = json.load(open(tpath)).get('body_sweep_hbm_bytes_per_launch')
             except Exception:  # noqa: BLE001
                 traffic = None
-        out = {
-            'metric': 'RF waveforms/sec StofNet inference rf_scale=10',
-            'value': round(value, 1), 'unit': 'waveforms/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'preheat_steps': PREHEAT_STEPS, 'ms_per_step': round(dt / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'fp32' else 'f32 via split-fp16 x3 MFMA operands (hi+lo, fp32 accumulate)',
-            'data': 'synthetic',
-            'config': {'workload': f'C2 StofNet.forward [{N_ROWS},1,{L}] -> [{N_ROWS},1,{L * R}] per GPU, '
-                                   f'upsample_factor={R}, SemiGlobalBlock on, seeded-random weights (seed 3008)',
-                       'rows_per_gpu': N_ROWS, 'L': L, 'upsample_factor': R, 'sharding': f'batch x{world}, no collective',
-                       'precision': args.precision},
-            'roofline': {'bound': 'mfma', 'kernel': 'body_sweep_kernel', 'achieved': round(achieved, 2),
-                         'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
-                         'flops_per_launch': body_flops(N_ROWS, L, R), 'avg_launch_ms': round(float(k_ms[2]), 4)},
-            'kernels_ms': {'sgb_contract_pool': round(float(k_ms[0]), 4), 'sgb_expand': round(float(k_ms[1]), 4),
-                           'body_sweep': round(float(k_ms[2]), 4)},
-            'whole_forward_tflops': round(total_flops(N_ROWS, L, R) * world * args.steps / dt / 1e12, 2),
-            'extras': {'picker_argmax_ms': round(pick_ms, 3),
-                       'waveforms_per_s_forward_plus_picker': round(world * N_ROWS / (dt / args.steps + pick_ms * 1e-3), 1),
-                       'index_gather_ms': None if gather_ms is None else round(gather_ms, 3),
-                       'fp32_exact_mode': fp32_extra},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sd, R, y, idx)
+        metric = 'RF waveforms/sec StofNet inference rf_scale=10'
+        if cfg == 'C3':
+            metric = 'RF waveforms/sec StofNet inference rf_scale=20'
+        if cfg == 'C4':
+            metric = 'RF waveforms/sec StofNet inference + onset picker, PALA shape'
+        out = base_line(args, d, metric, d.world * rows * args.steps / dt, dt, DTYPE_TEXT[args.precision], workload,
+                        {'rows_per_gpu': rows, 'L': L, 'upsample_factor': R, 'sharding': f'batch x{d.world}, no collective',
+                         'precision': args.precision})
+        out['preheat_steps'] = preheat
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'body_sweep_kernel', 'achieved': round(achieved, 2),
+                           'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
+                           'flops_per_launch': body_flops(launch_rows, L, R), 'avg_launch_ms': round(float(k_ms[2]), 4),
+                           'rows_per_launch': launch_rows}
+        out['kernels_ms'] = {'sgb_contract_pool': round(float(k_ms[0]), 4), 'sgb_expand': round(float(k_ms[1]), 4),
+                             'body_sweep': round(float(k_ms[2]), 4)}
+        out['whole_forward_tflops'] = round(total_flops(rows, L, R) * d.world * args.steps / dt / 1e12, 2)
+        out['extras'] = extras
+        if d.world == 1 and not args.no_cpu_baseline:
+            srows = 256 if cfg != 'C4' else 128
+            xs = x[:srows].cpu().numpy()
+            out['cpu_baseline'] = cpu_baseline(sd, R, L, xs, y[:srows] if cfg != 'C4' else model(x[:srows]),
+                                               idx[:srows], threshold=th)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    d.finish()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        return launch_children(args, argv)
+    if args.dry_run:
+        return dry_run(args)
+    if args.config == 'C5':
+        return train_bench(args)
+    return infer_bench(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

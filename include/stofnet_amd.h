@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STOF_ABI_VERSION 1
+#define STOF_ABI_VERSION 2
 
 typedef enum stof_status {
     STOF_OK = 0,
@@ -100,15 +100,27 @@ int stof_forward_checked(const stof_net_desc* desc, const void* packed_dev,
                          const float* x, float* y, int64_t N, int64_t L,
                          void* workspace, size_t workspace_bytes, void* stream, int32_t* status_dev);
 
+/* The default mode of the Python module (precision='auto'): STOF_PREC_F16X3 with the range guard of
+ * stof_forward_checked, followed by an exact STOF_PREC_FP32 re-run of the same call whose kernels are gated ON THE
+ * DEVICE by the guard word (they return at once while it is 0).  The result is the f16x3 map unless an activation left
+ * the fp16 range, in which case it is the fp32 map -- no host sync either way.  `desc->precision` is ignored; the two
+ * packed blobs come from stof_pack_weights with the respective precision.  *status_dev is zeroed by the call and reads
+ * 1 afterwards iff the fp32 re-run happened.  `events` may be NULL or as in stof_forward_events (f16x3 pass only).   */
+int stof_forward_auto(const stof_net_desc* desc, const void* packed_f16x3_dev, const void* packed_fp32_dev,
+                      const float* x, float* y, int64_t N, int64_t L, void* workspace, size_t workspace_bytes,
+                      void* stream, int32_t* status_dev, void* const* events);
+
 /* Same as stof_forward, with instrumentation for bench.py: `events` is an array of
  * STOF_FORWARD_EVENTS hipEvent_t recorded on `stream` before the first kernel and after each
  * kernel of the first sub-batch (SemiGlobalBlock contract+pool, expand, body sweep), so the
- * caller can read per-kernel durations with stof_event_elapsed_ms after a sync.
+ * caller can read per-kernel durations with stof_event_elapsed_ms after a sync.  `status_dev` may be NULL or
+ * the range-guard word of stof_forward_checked.
  * Wraps nothing in the reference (its only timing is time.process_time(), main.py:313-315). */
 #define STOF_FORWARD_EVENTS 4
 int stof_forward_events(const stof_net_desc* desc, const void* packed_dev,
                         const float* x, float* y, int64_t N, int64_t L,
-                        void* workspace, size_t workspace_bytes, void* stream, void* const* events);
+                        void* workspace, size_t workspace_bytes, void* stream, void* const* events,
+                        int32_t* status_dev);
 int stof_events_create(int32_t count, void** events_out);
 int stof_events_destroy(int32_t count, void* const* events);
 int stof_event_elapsed_ms(void* start, void* stop, float* ms_out);

@@ -48,7 +48,11 @@ _SIGNATURES = {
     'stof_forward_checked': (_c.c_int, [_c.POINTER(NetDesc), _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                         _c.c_int64, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p]),
     'stof_forward_events': (_c.c_int, [_c.POINTER(NetDesc), _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
-                                       _c.c_int64, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.POINTER(_c.c_void_p)]),
+                                       _c.c_int64, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.POINTER(_c.c_void_p),
+                                       _c.c_void_p]),
+    'stof_forward_auto': (_c.c_int, [_c.POINTER(NetDesc), _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
+                                     _c.c_int64, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
+                                     _c.POINTER(_c.c_void_p)]),
     'stof_events_create': (_c.c_int, [_c.c_int32, _c.POINTER(_c.c_void_p)]),
     'stof_events_destroy': (_c.c_int, [_c.c_int32, _c.POINTER(_c.c_void_p)]),
     'stof_event_elapsed_ms': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_float)]),

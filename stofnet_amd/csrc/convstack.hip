@@ -32,7 +32,7 @@
 namespace stof {
 int launch_conv_cl(const float* x, const float* w, const float* bias, const float* residual, const float* saved, float* y,
                    int64_t N, int64_t L, int32_t cin, int32_t cout, int32_t K, int32_t act, int32_t precision,
-                   int32_t period, int32_t valid_len, hipStream_t stream);
+                   int32_t period, int32_t valid_len, hipStream_t stream, const int* run_if);
 }
 
 using namespace stof;
@@ -155,6 +155,7 @@ struct BodyParams {
     int nseg_log2, seg_len, halo;
     unsigned long long* stamps;   // diagnostic builds (-DSTOF_STAMPS) only: [wg][wave][8] cycle sums
     int* status;                  // optional: bit 0 set if a non-finite output was produced (f16x3 range overflow)
+    const int* run_if;            // optional: the whole launch returns at once while *run_if == 0 ('auto' precision re-run)
 };
 
 template <int S, int RING, int RAWRING>
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
     const int n0 = blockIdx.x * p.wf_per_wg;
     const int n1 = min(p.N, n0 + p.wf_per_wg);
     if (n0 >= n1) return;
+    if (p.run_if != nullptr && *p.run_if == 0) return;
     const int Ltrue = p.L, r = p.r;
     const int L = p.seg_len + 2 * p.halo;        // rows of one (virtual) waveform in the stream
     const int Lp = L + GAP;
@@ -784,6 +786,7 @@ struct SgbParams {
     const float* cbias;    // [512]
     const float* chunks;   // [SGB_NCHUNK][SGB_CHUNK_F]
     int N, L, P, tiles_per_wf;
+    const int* run_if;     // as BodyParams::run_if
 };
 
 template <int PREC, int NW>
@@ -804,6 +807,7 @@ __global__ __launch_bounds__(256, SGB_WAVES_PER_SIMD) void sgb_contract_pool_ker
     const int w0 = (blockIdx.x - n * p.tiles_per_wf) * NW;
     const int L = p.L;
     const int tbase = SGB_SCALE * w0 - 2;         // time of act row 0
+    if (p.run_if != nullptr && *p.run_if == 0) return;
 
     const uint4* const wbase = reinterpret_cast<const uint4*>(p.chunks) + wave * 64 + lane;
     auto wload = [&](int c, int f) -> uint4 { return wbase[((size_t)c * FRAGS_PER_CHUNK + f) * 256]; };
@@ -939,7 +943,8 @@ constexpr size_t sgb_lds_bytes() {
 
 template <int PREC>
 int launch_forward(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y, int64_t N,
-                   int64_t L, void* workspace, hipStream_t stream, void* const* events, int32_t* status) {
+                   int64_t L, void* workspace, hipStream_t stream, void* const* events, int32_t* status,
+                   const int32_t* run_if) {
     const int force_nseg_log2 = desc->seg_policy > 0 ? desc->seg_policy - 1 : -1;
     const int r = desc->upsample_factor;
     const bool has_sgb = desc->semi_global_scale != 1;
@@ -984,12 +989,13 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
             sp.x = xb; sp.pooled = pooled; sp.c1 = c1; sp.cbias = cbias; sp.chunks = cchunks;
             sp.N = (int)nb; sp.L = (int)L; sp.P = (int)P;
             sp.tiles_per_wf = (int)((P + SGB_NW - 1) / SGB_NW);
+            sp.run_if = run_if;
             hipLaunchKernelGGL((sgb_contract_pool_kernel<PREC, SGB_NW>), dim3((unsigned)(nb * sp.tiles_per_wf)),
                                dim3(256), sgb_lds_bytes(), stream, sp);
             if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[1]), stream);
             {
                 const int st = stof::launch_conv_cl(pooled, ew, ebias, nullptr, nullptr, sgb, 1, nb * (P + 2), NF_SGB, NF, 5,
-                                                    /*act = leaky ReLU*/ 2, PREC, (int)(P + 2), (int)P, stream);
+                                                    /*act = leaky ReLU*/ 2, PREC, (int)(P + 2), (int)P, stream, run_if);
                 if (st != STOF_OK) return st;
             }
             if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[2]), stream);
@@ -1003,6 +1009,7 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         bp.N = (int)nb; bp.L = (int)L; bp.r = r; bp.P = (int)P; bp.rem_half = (int)(rem / 2);
         bp.stamps = nullptr;
         bp.status = status;
+        bp.run_if = run_if;
         // Cut every waveform into 2^k segments (each swept with +-38 rows of real context, the receptive field of
         // conv1 + 11 x k7 + conv_last) when that shortens the sweep: small batches, batches that do not fill the CUs evenly.
         // k is chosen to minimise the sweep steps of the busiest work-group (it also evens out batches that are not a
@@ -1043,7 +1050,8 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
 }
 
 int forward_impl(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y, int64_t N, int64_t L,
-                 void* workspace, size_t workspace_bytes, void* stream_, void* const* events, int32_t* status) {
+                 void* workspace, size_t workspace_bytes, void* stream_, void* const* events, int32_t* status,
+                 const int32_t* run_if = nullptr) {
     if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     if (desc->precision != STOF_PREC_FP32 && desc->precision != STOF_PREC_F16X3) return STOF_ERR_UNSUPPORTED;
     if (desc->seg_policy < 0 || desc->seg_policy > 6) return STOF_ERR_UNSUPPORTED;
@@ -1060,8 +1068,8 @@ int forward_impl(const stof_net_desc* desc, const void* packed_dev, const float*
         return STOF_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (desc->precision == STOF_PREC_FP32)
-        return launch_forward<STOF_PREC_FP32>(desc, packed_dev, x, y, N, L, workspace, stream, events, status);
-    return launch_forward<STOF_PREC_F16X3>(desc, packed_dev, x, y, N, L, workspace, stream, events, status);
+        return launch_forward<STOF_PREC_FP32>(desc, packed_dev, x, y, N, L, workspace, stream, events, status, run_if);
+    return launch_forward<STOF_PREC_F16X3>(desc, packed_dev, x, y, N, L, workspace, stream, events, status, run_if);
 }
 
 }  // namespace
@@ -1091,11 +1099,30 @@ extern "C" int stof_forward_checked(const stof_net_desc* desc, const void* packe
 
 extern "C" int stof_forward_events(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y,
                                    int64_t N, int64_t L, void* workspace, size_t workspace_bytes, void* stream,
-                                   void* const* events) {
+                                   void* const* events, int32_t* status_dev) {
     if (!events) return STOF_ERR_BAD_ARG;
     for (int e = 0; e < STOF_FORWARD_EVENTS; ++e)
         if (!events[e]) return STOF_ERR_BAD_ARG;
-    return forward_impl(desc, packed_dev, x, y, N, L, workspace, workspace_bytes, stream, events, nullptr);
+    return forward_impl(desc, packed_dev, x, y, N, L, workspace, workspace_bytes, stream, events, status_dev);
+}
+
+extern "C" int stof_forward_auto(const stof_net_desc* desc, const void* packed_f16x3_dev, const void* packed_fp32_dev,
+                                 const float* x, float* y, int64_t N, int64_t L, void* workspace, size_t workspace_bytes,
+                                 void* stream, int32_t* status_dev, void* const* events) {
+    if (!desc || !status_dev) return STOF_ERR_BAD_ARG;
+    if (events)
+        for (int e = 0; e < STOF_FORWARD_EVENTS; ++e)
+            if (!events[e]) return STOF_ERR_BAD_ARG;
+    stof_net_desc d16 = *desc, d32 = *desc;
+    d16.precision = STOF_PREC_F16X3;
+    d32.precision = STOF_PREC_FP32;
+    if (N > 0 && L > 0 && hipMemsetAsync(status_dev, 0, sizeof(int32_t), static_cast<hipStream_t>(stream)) != hipSuccess)
+        return STOF_ERR_HIP;
+    const int st = forward_impl(&d16, packed_f16x3_dev, x, y, N, L, workspace, workspace_bytes, stream, events, status_dev);
+    if (st != STOF_OK) return st;
+    // exact-fp32 re-run of the whole call, gated on the device by the range-guard word: its three launches return at
+    // once while *status_dev == 0, so the common case costs three empty launches and no host synchronisation
+    return forward_impl(&d32, packed_fp32_dev, x, y, N, L, workspace, workspace_bytes, stream, nullptr, nullptr, status_dev);
 }
 
 extern "C" int stof_events_create(int32_t count, void** events_out) {

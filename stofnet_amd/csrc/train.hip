@@ -73,6 +73,8 @@ struct ConvParams {
     // map to rows of a dense [N'][valid_len][C] tensor and the rest are zero gaps (>= K/2 rows, so blocks do not see
     // each other); used by the inference path for the SemiGlobalBlock expand conv on the pooled grid
     int period, valid_len;
+    const int* run_if;     // optional device flag: the launch does nothing while *run_if == 0 (fp32 re-run of the inference
+                           // path's 'auto' precision mode, decided on the device without a host sync)
 };
 
 // One work-group: CT = 128 time rows x 64 output channels; loops over 64-wide input-channel blocks and
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
     const int rows = CT + K - 1;
     const int ncb = (p.cin + 63) >> 6;
     const int nsteps = ncb * K;
+    if (p.run_if != nullptr && *p.run_if == 0) return;
 
     float4 wreg[4];
     auto wfetch = [&](int s) {
@@ -823,8 +826,9 @@ namespace stof {
 // Shared by the training entry point and by the inference forward (SemiGlobalBlock expand conv, stream mode).
 int launch_conv_cl(const float* x, const float* w, const float* bias, const float* residual, const float* saved, float* y,
                    int64_t N, int64_t L, int32_t cin, int32_t cout, int32_t K, int32_t act, int32_t precision,
-                   int32_t period, int32_t valid_len, hipStream_t stream) {
+                   int32_t period, int32_t valid_len, hipStream_t stream, const int* run_if) {
     ConvParams p;
+    p.run_if = run_if;
     p.x = x; p.w = w; p.bias = bias; p.residual = residual; p.saved = saved; p.y = y;
     p.N = (int)N; p.L = (int)L; p.cin = cin; p.cout = cout; p.K = K; p.act = act;
     p.period = period; p.valid_len = valid_len;
@@ -859,7 +863,7 @@ extern "C" int stof_train_conv(const float* x, const float* w_tapmajor, const fl
     if (N == 0 || L == 0) return STOF_OK;
     if (!x || !w_tapmajor || !y) return STOF_ERR_BAD_ARG;
     return stof::launch_conv_cl(x, w_tapmajor, bias, residual, saved, y, N, L, cin, cout, K, act, precision, 0, 0,
-                                static_cast<hipStream_t>(stream));
+                                static_cast<hipStream_t>(stream), nullptr);
 }
 
 extern "C" size_t stof_train_repack_floats(int32_t cout, int32_t cin, int32_t K, int32_t transpose_flip, int32_t precision) {

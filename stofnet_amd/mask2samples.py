@@ -12,14 +12,19 @@ from . import _lib
 _IDX_CAP = 32            # detections per row kept by the first pass; larger rows trigger a re-run
 
 
-def _pick(scores: torch.Tensor, window_size: int, threshold, cap: int):
+def _pick(scores: torch.Tensor, window_size: int, threshold, cap: int, counts=None, idx=None):
     _lib.require_device(scores, 'scores')
     if scores.dim() != 3 or scores.shape[1] != 1:
         raise RuntimeError('mask2coords expects scores of shape [N, 1, M] (utils/mask2samples.py:32)')
     s = scores.detach().contiguous().float()
     n, _, m = s.shape
-    counts = torch.empty((n,), dtype=torch.int32, device=s.device)
-    idx = torch.empty((n, max(cap, 1)), dtype=torch.int32, device=s.device)
+    if counts is None:
+        counts = torch.empty((n,), dtype=torch.int32, device=s.device)
+    if idx is None:
+        idx = torch.empty((n, max(cap, 1)), dtype=torch.int32, device=s.device)
+    if (counts.dtype != torch.int32 or idx.dtype != torch.int32 or counts.shape != (n,) or idx.dim() != 2
+            or idx.shape[0] != n or not counts.is_contiguous() or not idx.is_contiguous()):
+        raise ValueError('counts must be int32 [N], idx int32 [N, cap], both contiguous')
     has_th = 1 if threshold else 0                     # Q4: `if threshold:` (utils/mask2samples.py:16)
     with torch.cuda.device(s.device):
         _lib.check(_lib.lib().stof_pick_maxima(_lib.ptr(s), n, m, int(window_size), has_th,
@@ -35,6 +40,15 @@ def _pick_all(scores, window_size, threshold):
     if kmax > idx.shape[1]:
         s, counts, idx = _pick(scores, window_size, threshold, kmax)
     return s, counts, idx, kmax
+
+
+def pick_async(scores, window_size, threshold=None, cap=_IDX_CAP, counts=None, idx=None):
+    """get_maxima_positions without the reference's host sync (utils/mask2samples.py:93): returns (counts[N] int32,
+    idx[N, cap] int32) -- exact counts, the first `cap` detections of every row, entries beyond a row's count left as
+    they were -- optionally written into caller-provided buffers.  For pipelines that keep the GPU queue full
+    (bench.py C4); the caller checks counts.max() <= cap once at the end."""
+    _, counts, idx = _pick(scores, window_size, threshold, cap, counts, idx)
+    return counts, idx
 
 
 def get_maxima_positions(scores, window_size, threshold=None):

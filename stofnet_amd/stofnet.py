@@ -6,7 +6,14 @@ checkpoints load with `load_state_dict(strict=True)` (main.py:176-177) and
 `model.parameters()` / `.to(device)` / `.eval()` behave as in the reference.
 `forward` never calls those convs: it repacks the parameters once into the
 kernels' streaming layout (re-done when a parameter changes) and calls
-`stof_forward`.  Inference only: the result carries no autograd graph.
+`stof_forward*`.  Inference only: the result carries no autograd graph.
+
+`precision` (not in the reference, whose arithmetic is ATen fp32) selects the MFMA mode:
+  'auto'  (default) split-fp16 x3 operands with fp32 accumulation -- fp32-level accuracy at 3x the
+          fp32 MFMA rate -- plus a device-side range guard: if an activation leaves the fp16 range the
+          same call re-runs in exact fp32, decided on the GPU without a host sync (`stof_forward_auto`);
+  'fp32'  exact fp32 MFMA, the parity baseline;
+  'f16x3' the fast mode alone; `raise_if_overflow()` reports a range overflow.
 """
 from __future__ import annotations
 
@@ -20,7 +27,7 @@ import torch.nn.init as init
 from . import _lib
 from .sample_shuffle import SampleShuffle1D
 
-_PRECISIONS = {'fp32': _lib.PREC_FP32, 'f16x3': _lib.PREC_F16X3}
+_PRECISIONS = {'fp32': _lib.PREC_FP32, 'f16x3': _lib.PREC_F16X3, 'auto': _lib.PREC_F16X3}
 
 
 class SemiGlobalBlock(nn.Module):
@@ -46,7 +53,7 @@ class SemiGlobalBlock(nn.Module):
 class StofNet(nn.Module):
 
     def __init__(self, upsample_factor=4, num_features=64, num_blocks=13, kernel_sizes=[9, 7, 3], in_channels=1,
-                 semi_global_scale=80, weights_init=False, precision='fp32'):
+                 semi_global_scale=80, weights_init=False, precision='auto'):
         super().__init__()
         self.num_blocks = num_blocks
         self.in_channels = in_channels
@@ -68,8 +75,7 @@ class StofNet(nn.Module):
         self.residual_layers = list(range(3, num_blocks - 1, 2)) + [num_blocks - 1, num_blocks]
         if weights_init:
             self._initialize_weights()
-        self._packed = None
-        self._packed_key = None
+        self._packed = {}
         self._workspace = None
         self._status = None
 
@@ -90,17 +96,20 @@ class StofNet(nn.Module):
                    self.semi_global_block.expand_conv.weight, self.semi_global_block.expand_conv.bias]
         return ps
 
-    def _desc(self):
+    def _desc(self, prec=None):
         # 4th field: segment policy of the body sweep (0 = automatic; k+1 forces 2^k segments per waveform -- tests)
-        return _lib.NetDesc(int(self.upsample_factor), int(self.semi_global_scale), _PRECISIONS[self.precision],
-                            int(getattr(self, '_seg_policy', 0)))
+        return _lib.NetDesc(int(self.upsample_factor), int(self.semi_global_scale),
+                            _PRECISIONS[self.precision] if prec is None else prec, int(getattr(self, '_seg_policy', 0)))
 
-    def _packed_weights(self, device):
+    def _packed_weights(self, device, prec=None):
+        """Device blob of the parameters in the kernels' layout for MFMA mode `prec`; rebuilt when a parameter changes."""
+        prec = _PRECISIONS[self.precision] if prec is None else prec
         ps = self._param_list()
-        key = (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in ps)
-        if self._packed is None or self._packed_key != key:
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in ps)
+        hit = self._packed.get(prec)
+        if hit is None or hit[0] != key:
             lib = _lib.lib()
-            desc = self._desc()
+            desc = self._desc(prec)
             nbytes = lib.stof_packed_weights_bytes(ctypes.byref(desc))
             if nbytes == 0:
                 raise NotImplementedError('this StofNet configuration is not supported by the gfx950 kernels')
@@ -110,9 +119,8 @@ class StofNet(nn.Module):
                 arr[i] = h.ctypes.data
             blob = np.empty(nbytes, dtype=np.uint8)
             _lib.check(lib.stof_pack_weights(ctypes.byref(desc), arr, blob.ctypes.data, nbytes), 'stof_pack_weights')
-            self._packed = torch.from_numpy(blob).to(device)
-            self._packed_key = key
-        return self._packed
+            self._packed[prec] = (key, torch.from_numpy(blob).to(device))
+        return self._packed[prec][1]
 
     # ---- forward -------------------------------------------------------------
     def forward(self, x, _events=None):
@@ -132,11 +140,15 @@ class StofNet(nn.Module):
         ws_bytes = lib.stof_forward_workspace_bytes(ctypes.byref(desc), n, L)
         if self._workspace is None or self._workspace.numel() < ws_bytes or self._workspace.device != x.device:
             self._workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+        if self.precision != 'fp32' and (self._status is None or self._status.device != x.device):
+            self._status = torch.zeros(1, dtype=torch.int32, device=x.device)      # range-guard word of the split-fp16 modes
         with torch.cuda.device(x.device):
-            if _events is None and self.precision == 'f16x3':
-                # range guard of the split-fp16 mode: a device-side flag, checked by raise_if_overflow()
-                if self._status is None or self._status.device != x.device:
-                    self._status = torch.zeros(1, dtype=torch.int32, device=x.device)
+            if self.precision == 'auto':
+                packed32 = self._packed_weights(x.device, _lib.PREC_FP32)
+                code = lib.stof_forward_auto(ctypes.byref(desc), _lib.ptr(packed), _lib.ptr(packed32), _lib.ptr(xc),
+                                             _lib.ptr(y), n, L, _lib.ptr(self._workspace), self._workspace.numel(),
+                                             _lib.stream_ptr(x.device), _lib.ptr(self._status), _events)
+            elif _events is None and self.precision == 'f16x3':
                 code = lib.stof_forward_checked(ctypes.byref(desc), _lib.ptr(packed), _lib.ptr(xc), _lib.ptr(y), n, L,
                                                 _lib.ptr(self._workspace), self._workspace.numel(),
                                                 _lib.stream_ptr(x.device), _lib.ptr(self._status))
@@ -147,7 +159,8 @@ class StofNet(nn.Module):
             else:       # bench.py instrumentation: HIP events around each kernel on the launch stream
                 code = lib.stof_forward_events(ctypes.byref(desc), _lib.ptr(packed), _lib.ptr(xc), _lib.ptr(y), n, L,
                                                _lib.ptr(self._workspace), self._workspace.numel(),
-                                               _lib.stream_ptr(x.device), _events)
+                                               _lib.stream_ptr(x.device), _events,
+                                               _lib.ptr(self._status) if self.precision == 'f16x3' else None)
         if code == _lib.STOF_ERR_ODD_SGB_REMAINDER:
             # same failure as models/stofnet.py:115
             got = L // 80 * 80 + 2 * ((L - L // 80 * 80) // 2)
@@ -156,10 +169,14 @@ class StofNet(nn.Module):
         _lib.check(code, 'stof_forward')
         return y
 
+    def fell_back_to_fp32(self) -> bool:
+        """'auto' mode: synchronise and tell whether the LAST forward took the exact-fp32 re-run."""
+        return self.precision == 'auto' and self._status is not None and int(self._status.item()) != 0
+
     def raise_if_overflow(self):
         """f16x3 mode only: synchronise and raise if a forward since the last check produced non-finite
-        values (an activation left the fp16 range); re-run such inputs with precision='fp32'."""
-        if self._status is not None and int(self._status.item()) != 0:
+        values (an activation left the fp16 range); re-run such inputs with precision='fp32' (or use 'auto')."""
+        if self.precision == 'f16x3' and self._status is not None and int(self._status.item()) != 0:
             self._status.zero_()
             raise FloatingPointError("StofNet(precision='f16x3'): an activation exceeded the fp16 range; "
                                      "use precision='fp32' for this input")

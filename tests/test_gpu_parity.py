@@ -455,6 +455,29 @@ def test_f16x3_range_guard(dev):
     assert torch.isfinite(m32(x * 3.0e6)).all()             # the exact mode handles the same input
 
 
+def test_auto_precision_is_f16x3_with_device_side_fp32_rerun(dev):
+    """The module default: bits of the f16x3 mode on in-range inputs; on a range overflow the same call ends with the
+    exact-fp32 result (kernels gated on the device by the guard word, no host sync in forward)."""
+    from stofnet_amd import StofNet
+    assert StofNet().precision == 'auto'
+    sd = synth.synth_state_dict(4, seed=12)
+    x = torch.from_numpy(synth.synth_randn(300, 400, seed=5)).to(dev)
+    ma, m16, m32 = (make_model(dev, sd, 4, precision=p) for p in ('auto', 'f16x3', 'fp32'))
+    assert torch.equal(ma(x), m16(x)) and not ma.fell_back_to_fp32()
+    big = x * 3.0e6                                          # raw, un-normalised amplitudes: beyond fp16
+    ya = ma(big)
+    assert ma.fell_back_to_fp32()
+    assert torch.isfinite(ya).all() and torch.equal(ya, m32(big))
+    assert torch.equal(ma(x), m16(x)) and not ma.fell_back_to_fp32()      # the guard word is re-armed by every call
+    # no-SGB variant and N > 4096 (two sub-batches, overflow only in the second one)
+    sd1 = synth.synth_state_dict(4, seed=3, semi_global_scale=1)
+    mb, mb32 = make_model(dev, sd1, 4, 1, 'auto'), make_model(dev, sd1, 4, 1, 'fp32')
+    xl = torch.from_numpy(synth.synth_randn(4100, 160, seed=9)).to(dev)
+    xl[4098] *= 3.0e6
+    yb = mb(xl)
+    assert mb.fell_back_to_fp32() and torch.equal(yb, mb32(xl))
+
+
 def test_main_entry_point_end_to_end(dev, tmp_path):
     """`python main.py key=value ...` (reference README.md:25 style): config merge, checkpoint lookup by
     prefix with strict load, forward, mask2coords, device toa_rmse -- against the oracle chain."""
