@@ -38,8 +38,10 @@ typedef enum stof_status {
     STOF_ERR_UNSUPPORTED = 3,     /* shape/mode outside what the kernels implement              */
     STOF_ERR_WORKSPACE = 4,       /* workspace or packed-weight buffer too small                */
     STOF_ERR_HIP = 5,             /* a HIP runtime call or launch failed                        */
-    STOF_ERR_CHANNELS = 6         /* channel count not divisible by r (view error in the reference,
+    STOF_ERR_CHANNELS = 6,        /* channel count not divisible by r (view error in the reference,
                                       utils/sample_shuffle.py:24)                                */
+    STOF_ERR_POOL_EMPTY = 7       /* SemiGlobalBlock on a row shorter than one pooling window (L < 80): the reference's
+                                      MaxPool1d raises RuntimeError at models/stofnet.py:103       */
 } stof_status;
 
 const char* stof_status_string(int status);
@@ -155,22 +157,45 @@ size_t stof_hilbert_workspace_bytes(int64_t N, int64_t n);
 int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, float* re, float* im,
                  void* workspace, size_t workspace_bytes, void* stream);
 
-/* grad_peak_detect (models/gradpeak.py:8-68) on an envelope env[N, L].
- * Stage 1 computes the smoothed gradient (gradient spacing grad_step, Gaussian
- * sigma (2*grad_step-1)/6, taps from `taps` [2*radius+1] prepared by the host
- * exactly as models/gradpeak.py:71-76 does) into grad[N, L] and the batch sums
- * stats[2] = (sum, sum of squares) in double for the default threshold (Q7).  */
-int stof_gradpeak_gradient(const float* env, int64_t N, int64_t L, int32_t grad_step,
-                           const float* taps, int32_t radius, float* grad, double* stats,
-                           void* stream);
-/* Stage 2: threshold crossings + pairing per row.  echoes[N, cap, 3] =
- * (onset, peak, env[peak]) for the first `cap` echoes of each row, counts[N]
- * exact; flags[2] (zeroed by the caller): flags[0] is set to 1 if some row has edges but no surviving
- * candidate (Q9: the reference then returns an empty tensor for the batch), flags[1] = max(counts).  */
-int stof_gradpeak_pair(const float* env, const float* grad, int64_t N, int64_t L,
-                       float thres_pos, int32_t ival_min, int32_t ival_max,
-                       float* echoes, int64_t cap, int32_t* counts, int32_t* flags,
-                       void* stream);
+/* ------------------------------------------------------------------------- *
+ * GradPeak (models/gradpeak.py).  Common arguments:
+ *   grad_step, taps[2*radius+1], radius : gradient spacing g and the Gaussian taps for sigma = (2g-1)/6, prepared
+ *                                         by the host exactly as models/gradpeak.py:71-76 does (fp64 -> fp32)
+ *   ival_min, ival_max                  : hysteresis gate ival_min < peak - onset < ival_max (:20,:49)
+ *   echoes[N, cap, 3], counts[N]        : (onset, peak, env[peak]) of the first `cap` echoes of each row, exact counts
+ *   echo_max, reduced[N, echo_max, 3]   : echo_max > 0 also writes toa_detect's reduction (:107-114: echo_max largest
+ *                                         amplitudes, then ascending time, the reference's zero padding taking part);
+ *                                         the caller uses it iff flags[1] > echo_max
+ *   flags[2] (zeroed by the call)       : flags[0] = 1 if some row has edges but no surviving candidate (Q9: the
+ *                                         reference then returns an empty tensor for the batch), flags[1] = max(counts)
+ * Nothing synchronises with the host; one read of `flags` after the call tells the caller what to slice.
+ * ------------------------------------------------------------------------- */
+
+/* Pre-pass of the default threshold (Q7, models/gradpeak.py:18): adds the sum and the sum of squares of the smoothed
+ * gradient of env[N, L] to stats[0], stats[1] (double, zeroed by the caller; the caller puts N*L -- or the
+ * all-reduced values of a sharded batch -- into stats[0..2] = (sum, sum of squares, count)).                        */
+int stof_gradpeak_moments(const float* env, int64_t N, int64_t L, int32_t grad_step, const float* taps,
+                          int32_t radius, double* stats, void* stream);
+/* thres_pos = std**16 * 1.2e13 (:18) from stats[3] = (sum, sum of squares, count) into threshold_out[0], on the device. */
+int stof_gradpeak_threshold(const double* stats, float* threshold_out, void* stream);
+
+/* grad_peak_detect (models/gradpeak.py:8-68) on an envelope env[N, L]: gradient -> Gaussian blur -> threshold
+ * crossings -> hysteresis pairing in one launch (one wavefront per row).  The positive threshold is `threshold`, or
+ * *threshold_dev when that device pointer is non-NULL (the default threshold from stof_gradpeak_threshold).        */
+int stof_grad_peak_detect(const float* env, int64_t N, int64_t L, int32_t grad_step, const float* taps,
+                          int32_t radius, float threshold, const float* threshold_dev, int32_t ival_min,
+                          int32_t ival_max, int64_t echo_max, float* echoes, int64_t cap, float* reduced,
+                          int32_t* counts, int32_t* flags, void* stream);
+
+/* toa_detect (models/gradpeak.py:99-116) with an explicit threshold in ONE launch on waveforms frame[N, L]:
+ * Hilbert envelope (utils/hilbert.py:5-21) -> grad_peak_detect -> echo_max reduction; the envelope stays in LDS
+ * (env_out, optional [N, L], receives a copy).  Available when stof_toa_detect_fused_ok(L, radius) != 0 (even L with
+ * prime factors 2, 3, 5, a pair of rows within the LDS budget); otherwise STOF_ERR_UNSUPPORTED and the caller chains
+ * stof_hilbert + stof_grad_peak_detect.                                                                              */
+int stof_toa_detect_fused_ok(int64_t L, int32_t radius);
+int stof_toa_detect(const float* frame, int64_t N, int64_t L, int32_t grad_step, const float* taps, int32_t radius,
+                    float threshold, int32_t ival_min, int32_t ival_max, int64_t echo_max, float* echoes,
+                    int64_t cap, float* reduced, int32_t* counts, int32_t* flags, float* env_out, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Neighbours of the hot path (SURVEY.md section 8f "next rows").

@@ -21,6 +21,7 @@ STOF_ERR_UNSUPPORTED = 3
 STOF_ERR_WORKSPACE = 4
 STOF_ERR_HIP = 5
 STOF_ERR_CHANNELS = 6
+STOF_ERR_POOL_EMPTY = 7
 
 PREC_FP32 = 0
 PREC_F16X3 = 1
@@ -65,10 +66,16 @@ _SIGNATURES = {
     'stof_hilbert_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int64]),
     'stof_hilbert': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                 _c.c_void_p, _c.c_size_t, _c.c_void_p]),
-    'stof_gradpeak_gradient': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32,
-                                          _c.c_void_p, _c.c_void_p, _c.c_void_p]),
-    'stof_gradpeak_pair': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_int32,
-                                      _c.c_int32, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'stof_gradpeak_moments': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32,
+                                         _c.c_void_p, _c.c_void_p]),
+    'stof_gradpeak_threshold': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'stof_grad_peak_detect': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32,
+                                         _c.c_float, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_int64, _c.c_void_p,
+                                         _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'stof_toa_detect_fused_ok': (_c.c_int, [_c.c_int64, _c.c_int32]),
+    'stof_toa_detect': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32, _c.c_float,
+                                   _c.c_int32, _c.c_int32, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
+                                   _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'stof_iq2rf': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_double, _c.c_double, _c.c_double,
                               _c.c_int32, _c.c_void_p]),
     'stof_toa_rmse': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float,
@@ -120,7 +127,7 @@ def check(code: int, what: str = ''):
     if code == STOF_OK:
         return
     msg = f'{what}: {status_string(code)}' if what else status_string(code)
-    if code in (STOF_ERR_ODD_SGB_REMAINDER, STOF_ERR_CHANNELS, STOF_ERR_HIP, STOF_ERR_WORKSPACE):
+    if code in (STOF_ERR_ODD_SGB_REMAINDER, STOF_ERR_CHANNELS, STOF_ERR_HIP, STOF_ERR_WORKSPACE, STOF_ERR_POOL_EMPTY):
         raise RuntimeError(msg)          # torch raises RuntimeError for shape mismatches
     if code == STOF_ERR_UNSUPPORTED:
         raise NotImplementedError(msg)

@@ -1060,6 +1060,7 @@ int forward_impl(const stof_net_desc* desc, const void* packed_dev, const float*
     const bool has_sgb = desc->semi_global_scale != 1;
     if (has_sgb && desc->semi_global_scale != SGB_SCALE) return STOF_ERR_UNSUPPORTED;
     const int64_t P = L / SGB_SCALE;
+    if (has_sgb && L > 0 && P == 0) return STOF_ERR_POOL_EMPTY;        // the pooling fails before the add can (L = 79)
     if (has_sgb && ((L - P * SGB_SCALE) & 1)) return STOF_ERR_ODD_SGB_REMAINDER;
     if (N == 0 || L == 0) return STOF_OK;                 // empty batch: nothing to do
     if (!packed_dev || !x || !y) return STOF_ERR_BAD_ARG;

@@ -1,163 +1,261 @@
-// grad_peak_detect (models/gradpeak.py:8-68) in two gfx950 kernels.
+// GradPeak (models/gradpeak.py:8-133) on gfx950.
 //
-//   gradpeak_gradient : torch.gradient(env, spacing=g) (:14) -> Gaussian blur (:15, :89-96),
-//                       zero padded; also the batch-wide sum / sum of squares (double) that
-//                       the default threshold needs (:18, Q7).
-//   gradpeak_pair     : one wavefront per row walks the row 64 samples at a time and does the
-//                       whole hysteresis pairing (:23-60) with ballots: rising edges of
-//                       grad > th (onset candidates `ap`) and of grad < -th/4 (peaks `am`),
-//                       nearest preceding ap per am, interval gate, first am per distinct ap.
+//   gradpeak_rows_kernel<MOMENTS>   grad_peak_detect on envelope rows in HBM, one wavefront per row (gradpeak_core.h):
+//                                   MOMENTS = true is the pre-pass of the default threshold (Q7: the std of the WHOLE
+//                                   batch of smoothed gradients, :18), MOMENTS = false detects and pairs
+//   gradpeak_threshold_kernel       thres_pos = std**16 * 1.2e13 from the (all-reduced) moments, on the device
+//   toa_fused_kernel                toa_detect (:99-116) for an explicit threshold in ONE launch: a wavefront takes a
+//                                   pair of waveforms through FFT -> Hilbert filter -> inverse FFT (fft_small.h, LDS),
+//                                   turns the analytic signals into the two envelopes in place and streams them
+//                                   through gradient -> Gaussian blur -> threshold crossings -> hysteresis pairing ->
+//                                   echo_max reduction without the envelope ever leaving LDS
+// One host read per call at most (flags = {Q9, Kmax}); no host sync inside.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "stof_common.h"
+#include "stof_hip_util.h"
+#include "fft_small.h"
+#include "pair_io.h"
+#include "gradpeak_core.h"
+
+namespace stof {
+size_t hilbert_fast_lds_bytes(int64_t n, stof_fft::Plan* plan_out);      // hilbert.hip
+}
 
 namespace {
 
-constexpr int GP_CH = 2048;        // output samples per chunk in the gradient kernel
-constexpr int GP_MAXRAD = 96;
+using stof_gp::Config;
+using stof_gp::RowState;
+constexpr int LDS_BYTES = 160 * 1024;
+constexpr int ROWS_WAVES = 4;            // waves (= rows in flight) per work-group of gradpeak_rows_kernel
 
-__global__ __launch_bounds__(256) void gradpeak_gradient_kernel(const float* __restrict__ env, int L, float spacing,
-                                                                const float* __restrict__ taps, int radius,
-                                                                float* __restrict__ grad,
-                                                                double* __restrict__ stats) {
-    __shared__ float e[GP_CH + 2 * GP_MAXRAD + 2];
-    __shared__ float tp[2 * GP_MAXRAD + 1];
-    __shared__ double red[2][4];
+template <bool MOMENTS>
+__global__ __launch_bounds__(64 * ROWS_WAVES) void gradpeak_rows_kernel(const float* __restrict__ env, long long N, Config cf,
+                                                                        const float* __restrict__ taps,
+                                                                        const float* __restrict__ th_dev,
+                                                                        float* __restrict__ echoes, float* __restrict__ reduced,
+                                                                        int* __restrict__ counts, int* __restrict__ flags,
+                                                                        double* __restrict__ stats) {
+    __shared__ float rings[ROWS_WAVES][512];
+    __shared__ double red[2][ROWS_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t row = blockIdx.x;
-    const float* er = env + row * (size_t)L;
-    float* gr = grad + row * (size_t)L;
-    const int ntaps = 2 * radius + 1;
-    for (int i = tid; i < ntaps; i += 256) tp[i] = taps[i];
-    const float two_sp = 2.0f * spacing;
-    double s1 = 0.0, s2 = 0.0;
-    for (int c0 = 0; c0 < L; c0 += GP_CH) {
-        __syncthreads();
-        // e[i] <-> env[c0 - radius - 1 + i]
-        for (int i = tid; i < GP_CH + 2 * radius + 2; i += 256) {
-            const int t = c0 - radius - 1 + i;
-            e[i] = (t >= 0 && t < L) ? er[t] : 0.f;
-        }
-        __syncthreads();
-        for (int o = tid; o < GP_CH; o += 256) {
-            const int t = c0 + o;
-            if (t >= L) break;
-            float acc = 0.f;
-            for (int j = 0; j < ntaps; ++j) {
-                const int u = t + j - radius;            // gradient sample index
-                float g = 0.f;                           // zero padding of the blur (:94)
-                if (u >= 0 && u < L) {
-                    const int b = o + j + 1;             // e index of env[u]
-                    if (L == 1) g = 0.f;
-                    else if (u == 0) g = (e[b + 1] - e[b]) / spacing;
-                    else if (u == L - 1) g = (e[b] - e[b - 1]) / spacing;
-                    else g = (e[b + 1] - e[b - 1]) / two_sp;
-                }
-                acc = fmaf(tp[j], g, acc);
-            }
-            gr[t] = acc;
-            s1 += (double)acc;
-            s2 += (double)acc * (double)acc;
-        }
+    if (th_dev != nullptr) {                                   // default threshold computed on the device (Q7)
+        cf.th_pos = *th_dev;
+        cf.th_neg = -cf.th_pos / 4.0f;                          // models/gradpeak.py:19
     }
+    double mom[2] = {0.0, 0.0};
+    for (long long row = (long long)blockIdx.x * ROWS_WAVES + wave; row < N; row += (long long)gridDim.x * ROWS_WAVES) {
+        const float* e = env + row * (long long)cf.L;
+        float* const out[1] = {MOMENTS ? nullptr : echoes + row * cf.cap * 3};
+        RowState st[1];
+        stof_gp::stream_rows<1, MOMENTS>(
+            cf, taps, rings[wave], lane, [&](int u, float (&v)[1]) { v[0] = e[u]; }, [&](int, int i) { return e[i]; }, out, st, mom);
+        if constexpr (!MOMENTS) stof_gp::finish_row(st[0], cf, row, out[0], reduced, counts, flags, lane);
+    }
+    if (MOMENTS) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o);
-        s2 += __shfl_xor(s2, o);
-    }
-    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
-    __syncthreads();
-    if (tid == 0 && stats) {
-        atomicAdd(&stats[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(&stats[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        for (int o = 32; o > 0; o >>= 1) {
+            mom[0] += __shfl_xor(mom[0], o);
+            mom[1] += __shfl_xor(mom[1], o);
+        }
+        if (lane == 0) { red[0][wave] = mom[0]; red[1][wave] = mom[1]; }
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < ROWS_WAVES; ++w) { a += red[0][w]; b += red[1][w]; }
+            atomicAdd(&stats[0], a);
+            atomicAdd(&stats[1], b);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void gradpeak_pair_kernel(const float* __restrict__ env,
-                                                            const float* __restrict__ grad, int N, int L,
-                                                            float th_pos, float th_neg, int ival_min, int ival_max,
-                                                            float* __restrict__ echoes, long long cap,
-                                                            int* __restrict__ counts, int* __restrict__ flags) {
-    const int lane = threadIdx.x & 63;
-    const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
-    if (row >= N) return;                                   // whole wave exits together
-    const float* g = grad + row * (long long)L;
-    const float* e = env + row * (long long)L;
-    float* out = echoes + row * cap * 3;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const unsigned long long le_mask = lt_mask | (1ull << lane);
+// thres_pos = (grad_data.std() ** 16) * 1.2e13 (models/gradpeak.py:18): unbiased std of all N * L smoothed gradients
+// from stats = (sum, sum of squares, count), rounded to fp32 where torch rounds (std is an fp32 tensor, the power and
+// the product are fp32 operations); the 16th power is taken in double and rounded once (= a correctly rounded powf).
+__global__ void gradpeak_threshold_kernel(const double* __restrict__ stats, float* __restrict__ th_out) {
+    const double s1 = stats[0], s2 = stats[1], cnt = stats[2];
+    double var = (s2 - s1 * s1 / cnt) / (cnt > 1.0 ? cnt - 1.0 : 1.0);
+    if (!(var > 0.0)) var = 0.0;
+    const float sd = (float)sqrt(var);
+    double p = (double)sd;
+    p *= p; p *= p; p *= p; p *= p;                            // ** 16
+    const float p16 = (float)p;
+    th_out[0] = p16 * 1.2e13f;
+}
 
-    int last_ap = -1;          // most recent rising-slope edge seen so far (carry across chunks)
-    int last_kept_ap = -1;     // onset of the last surviving candidate (uniqueness, :58-59)
-    int nout = 0;
-    int any_ap = 0, any_am = 0;
-    for (int c0 = 0; c0 < L - 1; c0 += 64) {
-        const int i = c0 + lane;
-        bool ep = false, em = false;
-        if (i < L - 1) {
-            const float a = g[i], b = g[i + 1];
-            ep = !(a > th_pos) && (b > th_pos);             // diff(int(grad > th)) == 1  (:27,:29)
-            em = !(a < th_neg) && (b < th_neg);             // diff(int(grad < -th/4)) == 1 (:28,:30)
-        }
-        const unsigned long long pm = __ballot(ep);
-        const unsigned long long mm = __ballot(em);
-        any_ap |= (pm != 0);
-        any_am |= (mm != 0);
-        // nearest preceding (<=) onset candidate for this lane's peak candidate (:42-45)
-        const unsigned long long below = pm & le_mask;
-        const int ap = below ? (c0 + 63 - __builtin_clzll(below)) : last_ap;
-        const int gap = i - ap;
-        const bool valid = em && (ap >= 0) && (gap > ival_min) && (gap < ival_max);   // :48-49
-        const unsigned long long vm = __ballot(valid);
-        // onset of the previous surviving candidate (previous valid lane, else the carry)
-        const unsigned long long vbelow = vm & lt_mask;
-        const int prev_lane = vbelow ? (63 - __builtin_clzll(vbelow)) : 0;
-        const int prev_ap_lane = __shfl(ap, prev_lane);
-        const int prev_ap = vbelow ? prev_ap_lane : last_kept_ap;
-        const bool keep = valid && (ap != prev_ap);          // first am per distinct ap (:58-59)
-        const unsigned long long km = __ballot(keep);
-        if (keep) {
-            const int pos = nout + __builtin_popcountll(km & lt_mask);
-            if (pos < cap) {
-                out[3 * pos + 0] = (float)ap;
-                out[3 * pos + 1] = (float)i;
-                out[3 * pos + 2] = e[i];                     // data[i, am] (:66)
-            }
-        }
-        nout += __builtin_popcountll(km);
-        if (vm) last_kept_ap = __shfl(ap, 63 - __builtin_clzll(vm));
-        if (pm) last_ap = c0 + 63 - __builtin_clzll(pm);
+// ----------------------------------------------------------------------------------------------------------------
+// toa_detect fused: one wavefront per pair of waveforms, no work-group barrier after the table set-up
+// ----------------------------------------------------------------------------------------------------------------
+struct FusedParams {
+    const float* x;        // [N][L] waveforms
+    const float* taps;     // [2 rad + 1]
+    float* echoes;         // [N][cap][3]
+    float* reduced;        // [N][echo_max][3] or nullptr
+    int* counts;           // [N]
+    int* flags;            // {Q9, Kmax}
+    float* env_out;        // optional [N][L]: also store the envelope (debug / callers that want it)
+    long long N;
+    Config cf;
+    stof_fft::Plan plan;
+};
+
+// One work-group (T = 64, 128 or 256 threads) per pair of waveforms; after the transform wave r of the group streams
+// row r of the pair (a single-wave group takes both rows one after the other).
+__global__ __launch_bounds__(256, 4) void toa_fused_kernel(const FusedParams p) {
+    using namespace stof_fft;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int n = p.cf.L, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+    const int RG = stof_gp::ring_entries(p.cf.radius);
+    // LDS: pair image [n] | twiddle tables | two gradient rings
+    cf* const Z = reinterpret_cast<cf*>(lds);
+    cf* const ta = Z + n;
+    cf* const tb = ta + TW_A;
+    const int nb = (n + TW_A - 1) / TW_A;
+    float* const rings = reinterpret_cast<float*>(tb + nb);
+    for (int t = tid; t < TW_A + nb; t += T) {
+        const double k = t < TW_A ? (double)t : (double)(t - TW_A) * (double)TW_A;
+        double sn, cs;
+        sincospi(-2.0 * k / (double)n, &sn, &cs);
+        ta[t] = mk((float)cs, (float)sn);
     }
-    if (lane == 0) {
-        counts[row] = nout;
-        if (any_ap && any_am && nout == 0) atomicOr(&flags[0], 1);   // Q9 (:54-55)
-        if (nout > 0) atomicMax(&flags[1], nout);                    // Kmax of the batch (one host read for both)
+    const Twiddles tw{ta, tb};
+    const long long npairs = (p.N + 1) / 2;
+    for (long long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
+        const long long row = 2 * pr;
+        const float* xr = p.x + row * (size_t)n;
+        const bool second = row + 1 < p.N;
+        const float* const x2 = second ? xr + n : nullptr;
+        __syncthreads();                                          // tables built / previous pair fully consumed
+        stof_io::load_pair<4>(Z, xr, x2, n, tid, T);
+        __syncthreads();
+        analytic_in_place(Z, p.plan, tw, tid, T, [] { __syncthreads(); });
+        float* const eo = p.env_out ? p.env_out + row * (size_t)n : nullptr;
+        stof_io::unmix_pair<4>(                                   // analytic signals -> the two envelopes, in place
+            Z, xr, x2, n, tid, T,
+            [&](int q, const float (&xa)[4], const float (&v1)[4], const float (&xb)[4], const float (&v2)[4]) {
+                float ea[4], eb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ea[e] = stof_io::envelope(xa[e], v1[e]); eb[e] = stof_io::envelope(xb[e], v2[e]); }
+                float4* d = reinterpret_cast<float4*>(Z + 4 * q);
+                d[0] = make_float4(ea[0], eb[0], ea[1], eb[1]);
+                d[1] = make_float4(ea[2], eb[2], ea[3], eb[3]);
+                if (eo) {
+                    *reinterpret_cast<float4*>(eo + 4 * q) = make_float4(ea[0], ea[1], ea[2], ea[3]);
+                    if (second) *reinterpret_cast<float4*>(eo + n + 4 * q) = make_float4(eb[0], eb[1], eb[2], eb[3]);
+                }
+            },
+            [&](int i, float xa, float v1, float xb, float v2) {
+                const cf e = mk(stof_io::envelope(xa, v1), stof_io::envelope(xb, v2));
+                Z[i] = e;
+                if (eo) { eo[i] = e.x; if (second) eo[n + i] = e.y; }
+            });
+        __syncthreads();
+        const float* const E = reinterpret_cast<const float*>(Z);            // E[2 u + r] = envelope of row r at sample u
+        for (int r = wave; r < (second ? 2 : 1); r += nwaves) {
+            if (r >= 2) break;
+            float* const out[1] = {p.echoes + (row + r) * p.cf.cap * 3};
+            RowState st[1];
+            double mom[2] = {0.0, 0.0};
+            stof_gp::stream_rows<1, false>(
+                p.cf, p.taps, rings + (size_t)(wave & 1) * 2 * RG, lane, [&](int u, float (&v)[1]) { v[0] = E[2 * u + r]; },
+                [&](int, int i) { return E[2 * i + r]; }, out, st, mom);
+            stof_gp::finish_row(st[0], p.cf, row + r, out[0], p.reduced, p.counts, p.flags, lane);
+        }
     }
+}
+
+constexpr int FUSED_MAX_L = 4096;      // beyond this the envelope kernel + row-streaming kernel parallelise better
+
+size_t fused_lds_bytes(int64_t n, int radius, stof_fft::Plan* plan) {
+    if (n > FUSED_MAX_L || !stof::hilbert_fast_lds_bytes(n, plan)) return 0;
+    return ((size_t)n + stof_fft::twiddle_entries((int)n)) * sizeof(float2) + (size_t)2 * stof_gp::ring_floats(radius) * sizeof(float);
+}
+
+bool bad_common(int64_t N, int64_t L, int32_t grad_step, int32_t radius, int64_t cap) {
+    return N < 0 || L < 0 || radius < 0 || cap < 0 || grad_step <= 0;        // rescale_factor < 6: the reference fails too
+}
+
+Config make_config(int64_t L, int32_t grad_step, int32_t radius, float threshold, int32_t ival_min, int32_t ival_max,
+                   int64_t cap, int64_t echo_max) {
+    Config cf;
+    cf.L = (int)L; cf.spacing = (float)grad_step; cf.radius = radius;
+    cf.th_pos = threshold; cf.th_neg = -threshold / 4.0f;             // models/gradpeak.py:19
+    cf.ival_min = ival_min; cf.ival_max = ival_max; cf.cap = cap; cf.echo_max = echo_max > 0 ? echo_max : 0;
+    return cf;
 }
 
 }  // namespace
 
-extern "C" int stof_gradpeak_gradient(const float* env, int64_t N, int64_t L, int32_t grad_step,
-                                      const float* taps, int32_t radius, float* grad, double* stats,
-                                      void* stream) {
-    if (!env || !taps || !grad || N < 0 || L < 0 || radius < 0) return STOF_ERR_BAD_ARG;
-    if (grad_step <= 0) return STOF_ERR_BAD_ARG;       // rescale_factor < 6: the reference fails too
+extern "C" int stof_gradpeak_moments(const float* env, int64_t N, int64_t L, int32_t grad_step, const float* taps,
+                                     int32_t radius, double* stats, void* stream) {
+    if (!env || !taps || !stats || bad_common(N, L, grad_step, radius, 0)) return STOF_ERR_BAD_ARG;
     if (N == 0 || L == 0) return STOF_OK;
-    if (radius > GP_MAXRAD || N > 0x7fffffffLL || L > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(gradpeak_gradient_kernel, dim3((unsigned)N), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       env, (int)L, (float)grad_step, taps, (int)radius, grad, stats);
+    if (radius > stof_gp::MAXRAD || L > 0x3fffffffLL) return STOF_ERR_UNSUPPORTED;
+    const Config cf = make_config(L, grad_step, radius, 0.f, 0, 0, 0, 0);
+    int64_t grid = (N + ROWS_WAVES - 1) / ROWS_WAVES;
+    const int64_t maxg = (int64_t)stof::device_cu_count() * 8;
+    if (grid > maxg) grid = maxg;
+    hipLaunchKernelGGL(gradpeak_rows_kernel<true>, dim3((unsigned)grid), dim3(64 * ROWS_WAVES), 0,
+                       static_cast<hipStream_t>(stream), env, (long long)N, cf, taps, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       stats);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
-extern "C" int stof_gradpeak_pair(const float* env, const float* grad, int64_t N, int64_t L, float thres_pos,
-                                  int32_t ival_min, int32_t ival_max, float* echoes, int64_t cap,
-                                  int32_t* counts, int32_t* flags, void* stream) {
-    if (!env || !grad || !counts || !flags || (!echoes && cap > 0) || N < 0 || L < 0 || cap < 0)
+extern "C" int stof_gradpeak_threshold(const double* stats, float* threshold_out, void* stream) {
+    if (!stats || !threshold_out) return STOF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gradpeak_threshold_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), stats, threshold_out);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_grad_peak_detect(const float* env, int64_t N, int64_t L, int32_t grad_step, const float* taps,
+                                     int32_t radius, float threshold, const float* threshold_dev, int32_t ival_min,
+                                     int32_t ival_max, int64_t echo_max, float* echoes, int64_t cap, float* reduced,
+                                     int32_t* counts, int32_t* flags, void* stream) {
+    if (!env || !taps || !counts || !flags || (!echoes && cap > 0) || bad_common(N, L, grad_step, radius, cap))
         return STOF_ERR_BAD_ARG;
+    if (echo_max > 0 && !reduced) return STOF_ERR_BAD_ARG;
     if (N == 0) return STOF_OK;
-    if (N > 0x7fffffffLL || L > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
-    const float th_neg = -thres_pos / 4.0f;              // models/gradpeak.py:19
-    hipLaunchKernelGGL(gradpeak_pair_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), env, grad, (int)N, (int)L, thres_pos, th_neg,
-                       (int)ival_min, (int)ival_max, echoes, (long long)cap, counts, flags);
+    if (radius > stof_gp::MAXRAD || L > 0x3fffffffLL || N > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    const Config cf = make_config(L, grad_step, radius, threshold, ival_min, ival_max, cap, echo_max);
+    if (hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return STOF_ERR_HIP;
+    int64_t grid = (N + ROWS_WAVES - 1) / ROWS_WAVES;
+    const int64_t maxg = (int64_t)stof::device_cu_count() * 8;
+    if (grid > maxg) grid = maxg;
+    hipLaunchKernelGGL(gradpeak_rows_kernel<false>, dim3((unsigned)grid), dim3(64 * ROWS_WAVES), 0,
+                       static_cast<hipStream_t>(stream), env, (long long)N, cf, taps, threshold_dev, echoes, reduced, counts, flags,
+                       nullptr);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_toa_detect_fused_ok(int64_t L, int32_t radius) {
+    return fused_lds_bytes(L, radius, nullptr) != 0 && radius <= stof_gp::MAXRAD;
+}
+
+extern "C" int stof_toa_detect(const float* frame, int64_t N, int64_t L, int32_t grad_step, const float* taps, int32_t radius,
+                               float threshold, int32_t ival_min, int32_t ival_max, int64_t echo_max, float* echoes,
+                               int64_t cap, float* reduced, int32_t* counts, int32_t* flags, float* env_out, void* stream) {
+    if (!frame || !taps || !counts || !flags || (!echoes && cap > 0) || bad_common(N, L, grad_step, radius, cap))
+        return STOF_ERR_BAD_ARG;
+    if (echo_max > 0 && !reduced) return STOF_ERR_BAD_ARG;
+    if (N == 0) return STOF_OK;
+    if (N > 0x7fffffffLL || radius > stof_gp::MAXRAD) return STOF_ERR_UNSUPPORTED;
+    FusedParams p;
+    const size_t lds = fused_lds_bytes(L, radius, &p.plan);
+    if (!lds) return STOF_ERR_UNSUPPORTED;            // caller falls back to stof_hilbert + stof_grad_peak_detect
+    static stof::LdsLimitOnce once;
+    if (int st = once.ensure(reinterpret_cast<const void*>(&toa_fused_kernel), LDS_BYTES)) return st;
+    p.x = frame; p.taps = taps; p.echoes = echoes; p.reduced = echo_max > 0 ? reduced : nullptr;
+    p.counts = counts; p.flags = flags; p.env_out = env_out; p.N = N;
+    p.cf = make_config(L, grad_step, radius, threshold, ival_min, ival_max, cap, echo_max);
+    if (hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return STOF_ERR_HIP;
+    const int64_t npairs = (N + 1) / 2;
+    int64_t per_cu = (int64_t)LDS_BYTES / (int64_t)lds;
+    if (per_cu > 16) per_cu = 16;
+    int threads = 64;                                              // 16 waves per CU whatever the row length
+    while (threads < 256 && per_cu * (threads / 64) < 16) threads *= 2;
+    if (const char* e = getenv("STOF_FUSED_THREADS")) threads = atoi(e);       // tuning / A-B switch
+    int64_t grid = (int64_t)stof::device_cu_count() * per_cu;
+    if (grid > npairs) grid = npairs;
+    hipLaunchKernelGGL(toa_fused_kernel, dim3((unsigned)grid), dim3(threads), lds, static_cast<hipStream_t>(stream), p);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }

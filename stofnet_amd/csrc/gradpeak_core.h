@@ -1,0 +1,254 @@
+// grad_peak_detect (models/gradpeak.py:8-68) for one row per wavefront (or two rows that share one envelope image),
+// streamed 64 samples at a time -- device code shared by gradpeak.hip's stand-alone kernels (envelope rows in HBM) and
+// by the fused toa_detect kernel (envelope rows in LDS, straight out of the inverse FFT):
+//
+//   gradient  torch.gradient(env, spacing = g)  (:14): central differences / (2 g), one-sided / g at both ends,
+//             true IEEE divisions so every value is the reference's float
+//   blur      zero padded correlation with the 2 rad + 1 Gaussian taps (:15, :89-96), fmaf chain in tap order
+//   edges     rising edges of (blur > th) and (blur < -th/4) (:23-30) as 64-bit ballot masks; an edge sits at the
+//             last-false sample (diff == 1 at i means flag[i] = 0, flag[i + 1] = 1)
+//   pairing   every falling-slope edge `am` takes the nearest rising-slope edge `ap` <= am, gate
+//             ival_min < am - ap < ival_max, first am per distinct ap (:42-60)
+//
+// The smoothed gradient never leaves registers: gradients go through a small ring in LDS (the blur needs 2 rad + 1
+// neighbours), the two comparison flags of 64 consecutive samples are two ballots, and the pairing runs on those words
+// one iteration later (an edge at the last lane needs the first flag of the next word).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace stof_gp {
+
+constexpr int MAXRAD = 96;                      // Gaussian radius limit (sigma = (2 g - 1) / 6, rf_scale_factor <= 115)
+
+struct Config {
+    int L;                   // samples per row
+    float spacing;           // g
+    int radius;              // rad
+    float th_pos, th_neg;
+    int ival_min, ival_max;
+    long long cap;           // echoes kept per row in `echoes`
+    long long echo_max;      // > 0: also write the echo_max reduction (models/gradpeak.py:107-114) to `reduced`
+};
+
+// ring entries for a radius: the blur of 64 samples reads 64 + 2 rad gradients.  Every gradient is stored twice, at
+// slot and slot + ring_entries, so the 2 rad + 1 reads of a sample are `base + j` with no wrap arithmetic (one
+// ds_read with an immediate offset per tap); a row's ring therefore takes 2 * ring_entries floats.
+__host__ __device__ inline int ring_entries(int radius) { return radius <= 32 ? 128 : 256; }
+__host__ __device__ inline int ring_floats(int radius) { return 2 * ring_entries(radius); }
+
+struct RowState {
+    int last_ap = -1;          // most recent rising-slope edge seen so far (carry across words)
+    int last_kept_ap = -1;     // onset of the last surviving candidate (uniqueness, :58-59)
+    int nout = 0;
+    int any_ap = 0, any_am = 0;
+    unsigned long long P = 0, M = 0, V = 0;      // flags / validity of the previous word
+};
+
+__device__ __forceinline__ int msb64(unsigned long long v) { return 63 - __builtin_clzll(v); }
+
+// one word of the pairing: samples base .. base + 63, rising-slope edges EP, falling-slope edges EM
+template <class EnvAt>
+__device__ __forceinline__ void pair_word(RowState& st, int base, unsigned long long EP, unsigned long long EM, int lane,
+                                          const Config& cf, float* __restrict__ out, EnvAt env_at) {
+    st.any_ap |= (EP != 0);
+    st.any_am |= (EM != 0);
+    if (EM == 0) {                                           // wave-uniform: nothing to pair in this word
+        if (EP) st.last_ap = base + msb64(EP);
+        return;
+    }
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long le_mask = lt_mask | (1ull << lane);
+    const int i = base + lane;
+    const bool em = (EM >> lane) & 1ull;
+    // nearest preceding (<=) onset candidate for this lane's peak candidate (:42-45); the reference's 2**32 sentinel
+    // (:43, Q8) maps a peak without a preceding onset to the first onset, which the gap gate then rejects (gap < 0)
+    const unsigned long long below = EP & le_mask;
+    const int ap = below ? (base + msb64(below)) : st.last_ap;
+    const int gap = i - ap;
+    const bool valid = em && (ap >= 0) && (gap > cf.ival_min) && (gap < cf.ival_max);     // :48-49
+    const unsigned long long vm = __ballot(valid);
+    const unsigned long long vbelow = vm & lt_mask;
+    const int prev_ap_lane = __shfl(ap, vbelow ? msb64(vbelow) : 0);
+    const int prev_ap = vbelow ? prev_ap_lane : st.last_kept_ap;
+    const bool keep = valid && (ap != prev_ap);              // first am per distinct ap (:58-59)
+    const unsigned long long km = __ballot(keep);
+    if (keep) {
+        const long long pos = st.nout + __builtin_popcountll(km & lt_mask);
+        if (pos < cf.cap) {
+            out[3 * pos + 0] = (float)ap;
+            out[3 * pos + 1] = (float)i;
+            out[3 * pos + 2] = env_at(i);                    // data[i, am] (:66)
+        }
+    }
+    st.nout += __builtin_popcountll(km);
+    if (vm) st.last_kept_ap = __shfl(ap, msb64(vm));
+    if (EP) st.last_ap = base + msb64(EP);
+}
+
+// Streams NR rows (NR = 1, or 2 rows whose samples arrive together) through gradient -> blur -> flags -> pairing.
+//   env_pair(u, e)   : e[r] = envelope of row r at sample u, 0 <= u < L
+//   env_at(r, i)     : envelope of row r at sample i (amplitude of a kept peak)
+//   ring             : LDS, NR * ring_floats(radius) floats owned by this wave
+//   taps             : 2 rad + 1 floats in global memory (wave-uniform index: the compiler fetches them with scalar
+//                      loads and feeds them to the fmacs as SGPR operands)
+//   MOMENTS          : accumulate sum / sum of squares of the blurred gradient instead of pairing (Q7 pre-pass)
+template <int NR, bool MOMENTS, class EnvPair, class EnvAt>
+__device__ __forceinline__ void stream_rows(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring,
+                                            int lane, EnvPair env_pair, EnvAt env_at, float* const (&out)[NR],
+                                            RowState (&st)[NR], double (&mom)[2]) {
+    const int L = cf.L, rad = cf.radius;
+    const int RG = ring_entries(rad), rmask = RG - 1;
+    const float two_sp = 2.0f * cf.spacing;
+    // zero padding of the blur to the left of the row (:94): ring slots of the samples -2 rad .. -1
+    for (int q = lane; q < 2 * RG; q += 64) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) ring[r * 2 * RG + q] = 0.f;
+    }
+    const int cend = (L - 1 + rad) / 64 + 1;                  // one extra iteration flushes the last word
+    // the two envelope samples behind a gradient are fetched one iteration ahead, so that rows streamed from HBM pay
+    // the memory latency once and not once per 64 samples
+    float ea[NR], eb[NR];
+    auto fetch = [&](int u) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) ea[r] = eb[r] = 0.f;
+        if (u < L && L > 1) {
+            if (u == 0) { env_pair(1, ea); env_pair(0, eb); }
+            else if (u == L - 1) { env_pair(L - 1, ea); env_pair(L - 2, eb); }
+            else { env_pair(u + 1, ea); env_pair(u - 1, eb); }
+        }
+    };
+    fetch(lane);
+    for (int c = 0; c <= cend; ++c) {
+        const int u = 64 * c + lane;
+        float g[NR];
+        const float den = (u == 0 || u == L - 1) ? cf.spacing : two_sp;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) g[r] = (u < L && L > 1) ? (ea[r] - eb[r]) / den : 0.f;
+        fetch(u + 64);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            ring[r * 2 * RG + (u & rmask)] = g[r];
+            ring[r * 2 * RG + (u & rmask) + RG] = g[r];
+        }
+        // blurred gradient of sample i = u - rad from the gradients i - rad .. i + rad = u - 2 rad .. u
+        const int i = u - rad;
+        const bool in_row = (i >= 0) && (i < L);
+        float sm[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) sm[r] = 0.f;
+        // 2 rad + 1 taps, four at a time so that the ring reads of a group are in flight together; the fmaf chain keeps
+        // the tap order, i.e. the reference's rounding
+        const int ntaps = 2 * rad + 1, s0 = (u - 2 * rad) & rmask;
+        int j = 0;
+        for (; j + 4 <= ntaps; j += 4) {
+            const float t0 = taps[j], t1 = taps[j + 1], t2 = taps[j + 2], t3 = taps[j + 3];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float* rr = ring + r * 2 * RG + s0 + j;
+                const float g0 = rr[0], g1 = rr[1], g2 = rr[2], g3 = rr[3];
+                sm[r] = fmaf(t3, g3, fmaf(t2, g2, fmaf(t1, g1, fmaf(t0, g0, sm[r]))));
+            }
+        }
+        for (; j < ntaps; ++j) {
+            const float t = taps[j];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) sm[r] = fmaf(t, ring[r * 2 * RG + s0 + j], sm[r]);
+        }
+        if (MOMENTS) {
+            if (in_row) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) { mom[0] += (double)sm[r]; mom[1] += (double)sm[r] * (double)sm[r]; }
+            }
+            continue;
+        }
+        const unsigned long long V = __ballot(in_row && i < L - 1);       // an edge index is 0 .. L-2
+        const int base_prev = 64 * (c - 1) - rad;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const unsigned long long P = __ballot(in_row && sm[r] > cf.th_pos);     // grad > thres_pos (:23)
+            const unsigned long long M = __ballot(in_row && sm[r] < cf.th_neg);     // grad < thres_neg (:24)
+            if (c > 0) {
+                const unsigned long long EP = ~st[r].P & ((st[r].P >> 1) | (P << 63)) & st[r].V;
+                const unsigned long long EM = ~st[r].M & ((st[r].M >> 1) | (M << 63)) & st[r].V;
+                pair_word(st[r], base_prev, EP, EM, lane, cf, out[r], [&](int idx) { return env_at(r, idx); });
+            }
+            st[r].P = P; st[r].M = M; st[r].V = V;
+        }
+    }
+}
+
+// (not inlined: it runs once per row and would otherwise cost the streaming loop ~20 VGPRs = one wave per SIMD)
+// echo_max reduction of one row (models/gradpeak.py:107-114 when the batch-wide echo count exceeds echo_max): keep the
+// echo_max largest amplitudes, then ascending peak time -- with the reference's zero padding taking part: padded
+// entries have amplitude 0 and peak 0, so a row with fewer than echo_max echoes gets its zeros in FRONT.
+// `src` holds the row's min(nout, cap) echoes as written by this wave; they are re-read behind an L1-bypassing load.
+__device__ __attribute__((noinline)) void reduce_row(const float* src, long long cnt, long long k, float* __restrict__ dst, int lane) {
+    auto ld = [&](long long e, int f) {
+        const int bits = __hip_atomic_load(reinterpret_cast<const int*>(src) + 3 * e + f, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+        return __int_as_float(bits);
+    };
+    const long long npad = k > cnt ? k - cnt : 0;
+    for (long long p = lane; p < npad; p += 64) { dst[3 * p] = 0.f; dst[3 * p + 1] = 0.f; dst[3 * p + 2] = 0.f; }
+    if (cnt <= k) {
+        for (long long e = lane; e < cnt; e += 64)
+            for (int f = 0; f < 3; ++f) dst[3 * (npad + e) + f] = ld(e, f);
+        return;
+    }
+    // cnt > k: k rounds of "largest amplitude not yet taken" (ties: the earlier echo), lane owns entries lane + 64 t
+    const int nt = (int)((cnt + 63) / 64);
+    unsigned long long taken = 0;                             // bit t: entry lane + 64 t is selected (cnt <= 4096)
+    for (long long round = 0; round < k; ++round) {
+        float best = -1.f;
+        int best_e = 0x7fffffff;
+        for (int t = 0; t < nt && t < 64; ++t) {
+            const long long e = lane + 64ll * t;
+            if (e < cnt && !((taken >> t) & 1ull)) {
+                const float a = ld(e, 2);
+                if (a > best) { best = a; best_e = (int)e; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oe = __shfl_xor(best_e, o);
+            if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; }
+        }
+        if ((best_e & 63) == lane && best_e != 0x7fffffff) taken |= 1ull << (best_e >> 6);
+    }
+    long long pos = 0;
+    for (int t = 0; t < nt && t < 64; ++t) {
+        const bool sel = (taken >> t) & 1ull;
+        const unsigned long long sm = __ballot(sel);
+        const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (sel) {
+            const long long e = lane + 64ll * t, p = pos + __builtin_popcountll(sm & lt_mask);
+            for (int f = 0; f < 3; ++f) dst[3 * p + f] = ld(e, f);
+        }
+        pos += __builtin_popcountll(sm);
+    }
+}
+
+// end of a row: counts, batch flags (Q9, Kmax) and the optional reduction
+__device__ __forceinline__ void finish_row(const RowState& st, const Config& cf, long long row, float* __restrict__ out,
+                                           float* __restrict__ reduced, int* __restrict__ counts, int* __restrict__ flags,
+                                           int lane) {
+    // zero padding of the row up to `cap` (the reference pads with [0, 0, 0], :66)
+    for (long long q = 3ll * (st.nout < cf.cap ? st.nout : cf.cap) + lane; q < 3 * cf.cap; q += 64) out[q] = 0.f;
+    if (lane == 0) {
+        counts[row] = st.nout;
+        if (st.any_ap && st.any_am && st.nout == 0) atomicOr(&flags[0], 1);       // Q9 (:54-55)
+        // Kmax of the batch.  One atomic per row on ONE word serialises at ~90 per microsecond (4096 rows = the whole
+        // kernel); the word only grows, so a relaxed read first lets all but the first few record-setting rows skip it.
+        if (st.nout > 0 && st.nout > __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&flags[1], st.nout);
+    }
+    if (reduced != nullptr && cf.echo_max > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);                                            // this wave's echo stores have reached L2
+        const long long cnt = st.nout < cf.cap ? st.nout : cf.cap;
+        reduce_row(out, cnt, cf.echo_max, reduced + row * cf.echo_max * 3, lane);
+    }
+}
+
+}  // namespace stof_gp

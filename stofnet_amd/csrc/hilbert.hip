@@ -1,7 +1,16 @@
 // hilbert_transform (utils/hilbert.py:5-21): v = ifft(H .* fft(y)) along the last dim with
 //   H = [1, 2 (bins 1..n/2-1), 1 (bin n/2), 0 ...]            (Q6: for odd n bin n/2 is not doubled)
 //
-// One work-group per row; the row lives in LDS as complex fp32 for its whole life:
+// Two kernels:
+//   hilbert_pairs_kernel   (fast path: n even with prime factors 2, 3, 5 only and 8 n bytes within the LDS budget)
+//       one work-group per PAIR of rows; the pair rides one complex transform z = x1 + i x2 that lives in LDS; few
+//       passes of register butterflies of radix up to 25 with the filter fused into the middle pass (fft_small.h);
+//       twiddles from a two-level table the work-group builds in double precision.
+//   hilbert_generic_kernel (every other length: odd n, other prime factors, rows beyond LDS)
+//       stage-by-stage mixed radix (4, 2, 3, 5, then any prime) as described below; for rows that do not fit LDS the same
+//       stages run on a per-work-group scratch in global memory (L2 / Infinity Cache resident), so any n is served.
+//
+// hilbert_generic_kernel: one work-group per row (pair); the row lives in LDS as complex fp32 for its whole life:
 //   forward  : in-place decimation-in-frequency, mixed radix (4, 2, 3, 5, then any prime)
 //              -> spectrum in digit-reversed positions
 //   filter   : H[k]/n applied at each position's true frequency k
@@ -11,13 +20,17 @@
 // sincospi, rounded once).  Prime radices > 5 run as out-of-place O(R) sums per output
 // through a second LDS buffer.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "stof_common.h"
 #include "stof_hip_util.h"
+#include "fft_small.h"
+#include "pair_io.h"
 
 namespace {
 
 constexpr int MAX_STAGES = 24;
 constexpr int LDS_BYTES = 160 * 1024;
+constexpr int GENERIC_ZG_GRID = 512;     // work-groups of the global-scratch mode (2 per CU)
 
 struct FftPlan {
     int n;
@@ -197,15 +210,19 @@ __device__ void run_stage(float2*& cur, float2*& other, const float2* tw, int n,
 // returns the real part unchanged), i.e. Re = x1 - v2, Im = v1 + x2, hence v1 = Im - x2 and
 // v2 = x1 - Re: half the transforms per row.  For odd n (Q6: bin n/2 not doubled) the real part is
 // not preserved and every row gets its own transform.
-template <bool TW_LDS, bool PAIR>
-__global__ __launch_bounds__(512) void hilbert_kernel(const float* __restrict__ x, const float2* __restrict__ twg,
-                                                      const float* __restrict__ hf, const FftPlan plan,
-                                                      long long nrows, float* __restrict__ env,
-                                                      float* __restrict__ re, float* __restrict__ im) {
+// ZG: the row does not fit LDS; buf0 / buf1 are this work-group's slice of `scratch` (global memory).  The stages are
+// separated by __syncthreads(), whose work-group-scope release/acquire also orders the global accesses of one
+// work-group (all its waves share the CU's L1).
+template <bool TW_LDS, bool PAIR, bool ZG>
+__global__ __launch_bounds__(512) void hilbert_generic_kernel(const float* __restrict__ x, const float2* __restrict__ twg,
+                                                              const float* __restrict__ hf, const FftPlan plan,
+                                                              long long nrows, float* __restrict__ env,
+                                                              float* __restrict__ re, float* __restrict__ im,
+                                                              float2* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int n = plan.n;
-    float2* const buf0 = lds;
-    float2* const buf1 = lds + n;                                  // only used with a prime radix > 5
+    float2* const buf0 = ZG ? scratch + (size_t)blockIdx.x * 2 * (size_t)n : lds;
+    float2* const buf1 = buf0 + n;                                 // only used with a prime radix > 5
     const float2* tw = twg;
     if (TW_LDS) {
         float2* twl = lds + (plan.needs_second ? 2 : 1) * (size_t)n;
@@ -243,7 +260,7 @@ __global__ __launch_bounds__(512) void hilbert_kernel(const float* __restrict__ 
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const float2 v = cur[i];
             if (!PAIR) {
-                if (env) env[row * (size_t)n + i] = hypotf(v.x, v.y);
+                if (env) env[row * (size_t)n + i] = hypotf(v.x, v.y);        // torch.abs of a complex64
                 if (re) re[row * (size_t)n + i] = v.x;
                 if (im) im[row * (size_t)n + i] = v.y;
             } else {
@@ -262,11 +279,95 @@ __global__ __launch_bounds__(512) void hilbert_kernel(const float* __restrict__ 
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Fast path: one work-group per pair of rows, the pair's complex transform lives in LDS (fft_small.h).
+// PAIR un-mixing (even n): z = x1 + i x2, ifft(H fft(z)) = a1 + i a2 with a_j = x_j + i v_j the analytic signals,
+// so Re = x1 - v2, Im = v1 + x2, hence v1 = Im - x2, v2 = x1 - Re.
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void hilbert_pairs_kernel(const float* __restrict__ x, const stof_fft::Plan plan,
+                                                            long long nrows, float* __restrict__ env,
+                                                            float* __restrict__ re, float* __restrict__ im) {
+    using namespace stof_fft;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int n = plan.n, tid = threadIdx.x, T = blockDim.x;
+    cf* const Z = reinterpret_cast<cf*>(lds);
+    cf* const ta = Z + n;
+    cf* const tb = ta + TW_A;
+    const int nb = (n + TW_A - 1) / TW_A;
+    for (int t = tid; t < TW_A + nb; t += T) {                   // twiddle tables: double-precision sincospi, rounded once
+        const double k = t < TW_A ? (double)t : (double)(t - TW_A) * (double)TW_A;
+        double sn, cs;
+        sincospi(-2.0 * k / (double)n, &sn, &cs);
+        ta[t] = mk((float)cs, (float)sn);                        // tb follows ta in LDS
+    }
+    const Twiddles tw{ta, tb};
+    const long long npairs = (nrows + 1) / 2;
+    for (long long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
+        const long long row = 2 * pr;
+        const float* xr = x + row * (size_t)n;
+        const bool second = row + 1 < nrows;
+        __syncthreads();                                          // tables built / previous pair fully written out
+        const float* const x2 = second ? xr + n : nullptr;
+        stof_io::load_pair(Z, xr, x2, n, tid, T);
+        __syncthreads();
+        analytic_in_place(Z, plan, tw, tid, T, [] { __syncthreads(); });
+        float* const e1 = env ? env + row * (size_t)n : nullptr;
+        float* const r1 = re ? re + row * (size_t)n : nullptr;
+        float* const i1 = im ? im + row * (size_t)n : nullptr;
+        stof_io::unmix_pair(
+            Z, xr, x2, n, tid, T,
+            [&](int q, const float (&xa)[4], const float (&v1)[4], const float (&xb)[4], const float (&v2)[4]) {
+                using stof_io::envelope;
+                if (e1) {
+                    *reinterpret_cast<float4*>(e1 + 4 * q) = make_float4(envelope(xa[0], v1[0]), envelope(xa[1], v1[1]),
+                                                                         envelope(xa[2], v1[2]), envelope(xa[3], v1[3]));
+                    if (second)
+                        *reinterpret_cast<float4*>(e1 + n + 4 * q) = make_float4(envelope(xb[0], v2[0]), envelope(xb[1], v2[1]),
+                                                                                 envelope(xb[2], v2[2]), envelope(xb[3], v2[3]));
+                }
+                if (r1) {
+                    *reinterpret_cast<float4*>(r1 + 4 * q) = make_float4(xa[0], xa[1], xa[2], xa[3]);
+                    if (second) *reinterpret_cast<float4*>(r1 + n + 4 * q) = make_float4(xb[0], xb[1], xb[2], xb[3]);
+                }
+                if (i1) {
+                    *reinterpret_cast<float4*>(i1 + 4 * q) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+                    if (second) *reinterpret_cast<float4*>(i1 + n + 4 * q) = make_float4(v2[0], v2[1], v2[2], v2[3]);
+                }
+            },
+            [&](int i, float xa, float v1, float xb, float v2) {
+                if (e1) { e1[i] = stof_io::envelope(xa, v1); if (second) e1[n + i] = stof_io::envelope(xb, v2); }
+                if (r1) { r1[i] = xa; if (second) r1[n + i] = xb; }
+                if (i1) { i1[i] = v1; if (second) i1[n + i] = v2; }
+            });
+    }
+}
+
 }  // namespace
 
+namespace stof {
+// LDS bytes of the fast path for rows of n samples, 0 if n has no plan or does not fit (shared with gradpeak.hip)
+size_t hilbert_fast_lds_bytes(int64_t n, stof_fft::Plan* plan_out) {
+    if (n < 2 || n > LDS_BYTES / 8) return 0;
+    stof_fft::Plan p;
+    if (!stof_fft::make_plan((int)n, &p)) return 0;
+    const size_t bytes = ((size_t)n + stof_fft::twiddle_entries((int)n)) * sizeof(float2);
+    if (bytes > (size_t)LDS_BYTES) return 0;
+    if (plan_out) *plan_out = p;
+    return bytes;
+}
+}  // namespace stof
+
 extern "C" size_t stof_hilbert_workspace_bytes(int64_t N, int64_t n) {
-    (void)N;
-    return n > 0 ? (size_t)n * (sizeof(float2) + sizeof(float)) + 256 : 0;
+    if (n <= 0 || N <= 0) return 0;
+    if (stof::hilbert_fast_lds_bytes(n, nullptr)) return 256;                     // fast path: tables live in LDS
+    size_t bytes = (size_t)n * (sizeof(float2) + sizeof(float)) + 256;             // twiddle + filter tables
+    if ((size_t)n * sizeof(float2) > (size_t)LDS_BYTES / 2 || n > LDS_BYTES / 8) {
+        // rows that may not fit LDS (two buffers when a prime radix > 5 is present): per-work-group global scratch
+        const int64_t units = (n % 2 == 0) ? (N + 1) / 2 : N;
+        const int64_t grid = units < GENERIC_ZG_GRID ? units : GENERIC_ZG_GRID;
+        bytes += (size_t)grid * 2 * (size_t)n * sizeof(float2);
+    }
+    return bytes;
 }
 
 extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, float* re, float* im,
@@ -275,30 +376,60 @@ extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, fl
     if (N == 0 || n == 0) return STOF_OK;
     if (!x || (!env && !re && !im)) return STOF_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < stof_hilbert_workspace_bytes(N, n)) return STOF_ERR_WORKSPACE;
-    if (N > 0x7fffffffLL || n > LDS_BYTES / 8) return STOF_ERR_UNSUPPORTED;
+    if (N > 0x7fffffffLL || n > (1 << 22)) return STOF_ERR_UNSUPPORTED;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int ncu = stof::device_cu_count();
+
+    stof_fft::Plan fplan;
+    if (const size_t flds = stof::hilbert_fast_lds_bytes(n, &fplan)) {
+        static stof::LdsLimitOnce fast_once;
+        if (int st = fast_once.ensure(reinterpret_cast<const void*>(&hilbert_pairs_kernel), LDS_BYTES)) return st;
+        // threads per pair: enough waves per CU to hide LDS latency whatever the row length
+        int per_cu = (int)((size_t)LDS_BYTES / flds);
+        if (per_cu > 16) per_cu = 16;
+        int threads = 64;                                          // 16 waves per CU whatever the row length
+        while (threads < 512 && per_cu * (threads / 64) < 16) threads *= 2;
+        if (const char* e = getenv("STOF_HILBERT_THREADS")) threads = atoi(e);       // tuning / A-B switch
+        const int64_t npairs = (N + 1) / 2;
+        int64_t grid = (int64_t)ncu * per_cu;
+        if (grid > npairs) grid = npairs;
+        hipLaunchKernelGGL(hilbert_pairs_kernel, dim3((unsigned)grid), dim3(threads), flds, stream, x, fplan, (long long)N,
+                           env, re, im);
+        return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+    }
+
     FftPlan plan;
     make_plan((int)n, &plan);
     const size_t data_lds = (size_t)n * sizeof(float2) * (plan.needs_second ? 2 : 1);
-    if (data_lds > (size_t)LDS_BYTES) return STOF_ERR_UNSUPPORTED;      // prime factor > 5 and n > 10240
-    const bool tw_lds = data_lds + (size_t)n * sizeof(float2) <= (size_t)LDS_BYTES;
-    const size_t lds = data_lds + (tw_lds ? (size_t)n * sizeof(float2) : 0);
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const bool zg = data_lds > (size_t)LDS_BYTES;                                    // row (pair) beyond LDS: global scratch
+    const bool tw_lds = !zg && data_lds + (size_t)n * sizeof(float2) <= (size_t)LDS_BYTES;
+    const size_t lds = zg ? 0 : data_lds + (tw_lds ? (size_t)n * sizeof(float2) : 0);
     const bool pair = (n % 2 == 0);
-    using Kern = void (*)(const float*, const float2*, const float*, const FftPlan, long long, float*, float*, float*);
-    const Kern kern = tw_lds ? (pair ? &hilbert_kernel<true, true> : &hilbert_kernel<true, false>)
-                             : (pair ? &hilbert_kernel<false, true> : &hilbert_kernel<false, false>);
-    static stof::LdsLimitOnce lds_once[4];
-    if (int st = lds_once[(tw_lds ? 2 : 0) + (pair ? 1 : 0)].ensure(reinterpret_cast<const void*>(kern), LDS_BYTES)) return st;
+    using Kern = void (*)(const float*, const float2*, const float*, const FftPlan, long long, float*, float*, float*, float2*);
+    const Kern kern = zg ? (pair ? &hilbert_generic_kernel<false, true, true> : &hilbert_generic_kernel<false, false, true>)
+                    : tw_lds ? (pair ? &hilbert_generic_kernel<true, true, false> : &hilbert_generic_kernel<true, false, false>)
+                             : (pair ? &hilbert_generic_kernel<false, true, false> : &hilbert_generic_kernel<false, false, false>);
+    if (!zg) {
+        static stof::LdsLimitOnce lds_once[4];
+        if (int st = lds_once[(tw_lds ? 2 : 0) + (pair ? 1 : 0)].ensure(reinterpret_cast<const void*>(kern), LDS_BYTES)) return st;
+    }
     float2* tw = static_cast<float2*>(workspace);
     float* hf = reinterpret_cast<float*>(tw + n);
+    float2* scratch = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) +
+                                                ((size_t)n * (sizeof(float2) + sizeof(float)) + 255) / 256 * 256);
     hipLaunchKernelGGL(tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, hf, plan);
-    // persistent-ish grid: as many work-groups as can be resident (LDS-limited), each looping over rows
-    int64_t per_cu = (int64_t)LDS_BYTES / (int64_t)(lds ? lds : 1);
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu = 4;                                          // 512 threads x 4 = 32 waves per CU
-    int64_t grid = 256 * per_cu;
     const int64_t units = pair ? (N + 1) / 2 : N;
-    if (grid > units) grid = units;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, x, tw, hf, plan, (long long)N, env, re, im);
+    int64_t grid;
+    if (zg) {
+        grid = units < GENERIC_ZG_GRID ? units : GENERIC_ZG_GRID;
+    } else {
+        // persistent-ish grid: as many work-groups as can be resident (LDS-limited), each looping over rows
+        int64_t per_cu = (int64_t)LDS_BYTES / (int64_t)(lds ? lds : 1);
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 4) per_cu = 4;                                      // 512 threads x 4 = 32 waves per CU
+        grid = ncu * per_cu;
+        if (grid > units) grid = units;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, x, tw, hf, plan, (long long)N, env, re, im, scratch);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }

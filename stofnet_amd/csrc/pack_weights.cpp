@@ -167,6 +167,7 @@ extern "C" const char* stof_status_string(int status) {
         case STOF_ERR_WORKSPACE: return "workspace or packed-weight buffer too small";
         case STOF_ERR_HIP: return "HIP runtime error";
         case STOF_ERR_CHANNELS: return "input channels not divisible by upsample_factor";
+        case STOF_ERR_POOL_EMPTY: return "max_pool1d() Invalid computed output size: 0";
         default: return "unknown status";
     }
 }

@@ -36,71 +36,93 @@ def _taps_on(device, grad_step):
     return _TAPS[key]
 
 
-def grad_peak_detect(data, grad_step: int = None, threshold: float = None, ival_smin: int = None,
-                     ival_smax: int = None):
-    """models/gradpeak.py:8-68 -> [N, Kmax, 3] = (onset, peak, amplitude), zero padded."""
+def _moment_reduce(stats, group):
+    """Q7 across ranks: the default threshold is the std of the WHOLE batch (models/gradpeak.py:18), so a sharded
+    batch sums its three moments (sum, sum of squares, count) over the ranks before the threshold is formed."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    return stats
+
+
+def _detect(frame_or_env, is_frame, grad_step, threshold, ival, echo_max, group=None):
+    """Shared driver of grad_peak_detect (envelope in) and toa_detect (waveform in): returns what the reference's
+    grad_peak_detect + the echo_max block of toa_detect return.  One host read (flags) per call."""
+    data = frame_or_env
     _lib.require_device(data, 'data')
-    env = data.detach().contiguous().float()
-    n, L = env.shape
-    grad_step = grad_step if grad_step is not None else 2
-    taps = _taps_on(env.device, grad_step)
+    x = data.detach().contiguous().float()
+    n, L = x.shape
+    taps = _taps_on(x.device, grad_step)
     radius = (taps.numel() - 1) // 2
     lib = _lib.lib()
-    grad = torch.empty_like(env)
-    stats = torch.zeros(2, dtype=torch.float64, device=env.device)
-    stream = _lib.stream_ptr(env.device)
-    with torch.cuda.device(env.device):
-        _lib.check(lib.stof_gradpeak_gradient(_lib.ptr(env), n, L, int(grad_step), _lib.ptr(taps), radius,
-                                              _lib.ptr(grad), _lib.ptr(stats), stream), 'stof_gradpeak_gradient')
-    if threshold is not None:
-        thres_pos = float(threshold)
+    stream = _lib.stream_ptr(x.device)
+    emax = int(echo_max) if (echo_max is not None and echo_max != float('inf') and echo_max >= 1) else 0
+    fused = bool(is_frame and threshold is not None and lib.stof_toa_detect_fused_ok(L, radius))
+    env = None
+    th_dev = None
+    with torch.cuda.device(x.device):
+        if not fused:
+            env = hilbert_envelope(x) if is_frame else x
+            if threshold is None:
+                # Q7: (unbiased std of the WHOLE batch tensor) ** 16 * 1.2e13 (models/gradpeak.py:18), formed on the device
+                stats = torch.tensor([0.0, 0.0, float(n * L)], dtype=torch.float64, device=x.device)
+                _lib.check(lib.stof_gradpeak_moments(_lib.ptr(env), n, L, int(grad_step), _lib.ptr(taps), radius,
+                                                     _lib.ptr(stats), stream), 'stof_gradpeak_moments')
+                _moment_reduce(stats, group)
+                th_dev = torch.empty(1, dtype=torch.float32, device=x.device)
+                _lib.check(lib.stof_gradpeak_threshold(_lib.ptr(stats), _lib.ptr(th_dev), stream), 'stof_gradpeak_threshold')
+
+        def run(cap):
+            echoes = torch.empty((n, cap, 3), dtype=torch.float32, device=x.device)
+            reduced = torch.empty((n, emax, 3), dtype=torch.float32, device=x.device) if emax else None
+            counts = torch.empty((n,), dtype=torch.int32, device=x.device)
+            flags = torch.empty((2,), dtype=torch.int32, device=x.device)
+            th = float(threshold) if threshold is not None else 0.0
+            if fused:
+                code = lib.stof_toa_detect(_lib.ptr(x), n, L, int(grad_step), _lib.ptr(taps), radius, th, ival[0], ival[1],
+                                           emax, _lib.ptr(echoes), cap, _lib.ptr(reduced), _lib.ptr(counts),
+                                           _lib.ptr(flags), None, stream)
+            else:
+                code = lib.stof_grad_peak_detect(_lib.ptr(env), n, L, int(grad_step), _lib.ptr(taps), radius, th,
+                                                 _lib.ptr(th_dev), ival[0], ival[1], emax, _lib.ptr(echoes), cap,
+                                                 _lib.ptr(reduced), _lib.ptr(counts), _lib.ptr(flags), stream)
+            _lib.check(code, 'stof_toa_detect' if fused else 'stof_grad_peak_detect')
+            return echoes, reduced, flags
+
+        echoes, reduced, flags = run(_CAP)
+        q9, kmax = (int(v) for v in flags.cpu()) if n else (0, 0)        # the one host read (reference: :35-66 python loop)
+        if kmax > _CAP and not q9:
+            echoes, reduced, flags = run(kmax)
+    if q9:
+        # Q9 (models/gradpeak.py:54-55): the reference returns an empty [3, 0] tensor for the whole batch
+        return torch.tensor([[], [], []])
+    if kmax == 0:
+        return torch.zeros((n, 0), dtype=x.dtype, device=x.device)       # shape the reference builds (:66)
+    if echo_max is not None and kmax > echo_max:                          # toa_detect's reduction (:107-114)
+        out = reduced if emax else echoes[:, :0]
     else:
-        # Q7: (unbiased std of the WHOLE batch tensor) ** 16 * 1.2e13, in float32 (models/gradpeak.py:18)
-        s1, s2 = (float(v) for v in stats.cpu())
-        cnt = n * L
-        var = max(s2 - s1 * s1 / cnt, 0.0) / max(cnt - 1, 1)
-        std = np.float32(math.sqrt(var))
-        with np.errstate(over='ignore', under='ignore'):
-            thres_pos = float(np.float32(np.float32(std ** np.float32(16)) * np.float32(1.2e13)))
+        out = echoes[:, :kmax]
+    return out.to(data.dtype)
+
+
+def grad_peak_detect(data, grad_step: int = None, threshold: float = None, ival_smin: int = None,
+                     ival_smax: int = None, group=None):
+    """models/gradpeak.py:8-68 -> [N, Kmax, 3] = (onset, peak, amplitude), zero padded.  `group`: process group of a
+    batch sharded over ranks (default group if torch.distributed is initialised)."""
+    grad_step = grad_step if grad_step is not None else 2
     if ival_smin is not None and ival_smax is not None:
         ival = (int(ival_smin), int(ival_smax))
     else:
         ival = (grad_step // 2, grad_step * 3)
-
-    def run(cap):
-        echoes = torch.zeros((n, cap, 3), dtype=torch.float32, device=env.device)
-        counts = torch.empty((n,), dtype=torch.int32, device=env.device)
-        flags = torch.zeros((2,), dtype=torch.int32, device=env.device)
-        with torch.cuda.device(env.device):
-            _lib.check(lib.stof_gradpeak_pair(_lib.ptr(env), _lib.ptr(grad), n, L, thres_pos, ival[0], ival[1],
-                                              _lib.ptr(echoes), cap, _lib.ptr(counts), _lib.ptr(flags), stream),
-                       'stof_gradpeak_pair')
-        return echoes, counts, flags
-
-    echoes, counts, flags = run(_CAP)
-    q9, kmax = (int(v) for v in flags.cpu()) if n else (0, 0)        # the one host sync (reference: :35-66 python loop)
-    if q9:
-        # Q9 (models/gradpeak.py:54-55): the reference returns an empty [3, 0] tensor for the whole batch
-        return torch.tensor([[], [], []])
-    if kmax > _CAP:
-        echoes, counts, flags = run(kmax)
-    if kmax == 0:
-        return torch.zeros((n, 0), dtype=env.dtype, device=env.device)   # shape the reference builds (:66)
-    return echoes[:, :kmax].to(data.dtype)
+    return _detect(data, False, grad_step, threshold, ival, None, group)
 
 
-def toa_detect(frame, threshold=None, rescale_factor=1, echo_max=float('inf')):
-    """models/gradpeak.py:99-116."""
-    hilbert_data = hilbert_envelope(frame)
-    echoes = grad_peak_detect(hilbert_data, grad_step=rescale_factor // 6 * 5, ival_smin=rescale_factor,
-                              ival_smax=50 * rescale_factor, threshold=threshold)
-    echo_num = echoes.shape[1]
-    if echo_num > echo_max:
-        idcs = torch.argsort(echoes[..., -1], descending=True, dim=1)
-        echoes = torch.gather(echoes, dim=1, index=idcs[..., None].repeat(1, 1, 3))[:, :echo_max]
-        idcs = torch.argsort(echoes[..., 1], descending=False, dim=1)
-        echoes = torch.gather(echoes, dim=1, index=idcs[..., None].repeat(1, 1, 3))
-    return echoes
+def toa_detect(frame, threshold=None, rescale_factor=1, echo_max=float('inf'), group=None):
+    """models/gradpeak.py:99-116: Hilbert envelope -> grad_peak_detect -> top-`echo_max` echoes by amplitude in time
+    order.  With an explicit threshold and a row length the fused kernel supports this is ONE launch (stof_toa_detect);
+    otherwise envelope kernel + (moments + threshold +) detection kernel.  Nothing here runs on ATen."""
+    return _detect(frame, True, rescale_factor // 6 * 5, threshold, (int(rescale_factor), 50 * int(rescale_factor)),
+                   echo_max, group)
 
 
 class GradPeak(torch.nn.Module):

@@ -166,6 +166,8 @@ class StofNet(nn.Module):
             got = L // 80 * 80 + 2 * ((L - L // 80 * 80) // 2)
             raise RuntimeError(f'The size of tensor a ({L}) must match the size of tensor b ({got}) at '
                                f'non-singleton dimension 2')
+        if code == _lib.STOF_ERR_POOL_EMPTY:
+            raise RuntimeError(_lib.status_string(code))      # the reference's message (models/stofnet.py:103)
         _lib.check(code, 'stof_forward')
         return y
 

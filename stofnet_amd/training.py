@@ -218,7 +218,7 @@ class StofNetTrainer:
                                                    _lib.ptr(self.exp_avg_sq), self.flat.numel(), self.lr, self.betas[0],
                                                    self.betas[1], self.eps, self.wd, self.step_count, self._st()),
                        'stof_train_adamw')
-        self.model._packed = None                              # inference weights must be repacked
+        self.model._packed = {}                                # inference weights must be repacked
 
     def train_step(self, frame, gt_true):
         loss, pred = self.forward_backward(frame, gt_true)

@@ -32,14 +32,16 @@ def report(name, nbytes, sec, **kw):
 
 
 N = 4096
-for r in (4, 10, 20):
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ''
+for r in (() if ONLY else (4, 10, 20)):
     x = torch.randn(N, r, 2000, device=dev)
     shuf = SampleShuffle1D(r)
     report(f'sample_shuffle r={r} [{N},{r},2000]', 2 * x.numel() * 4, timeit(lambda: shuf(x)))
-x = torch.randn(N, 64, 500, device=dev)
-shuf = SampleShuffle1D(4)
-report('sample_shuffle r=4 C=16 [4096,64,500] (EDSR shape)', 2 * x.numel() * 4, timeit(lambda: shuf(x)))
-for M in (8000, 20000, 40000):
+if not ONLY:
+    x = torch.randn(N, 64, 500, device=dev)
+    shuf = SampleShuffle1D(4)
+    report('sample_shuffle r=4 C=16 [4096,64,500] (EDSR shape)', 2 * x.numel() * 4, timeit(lambda: shuf(x)))
+for M in (() if ONLY else (8000, 20000, 40000)):
     y = torch.randn(N, 1, M, device=dev)
     report(f'pick_maxima argmax [{N},1,{M}]', y.numel() * 4, timeit(lambda: onset_indices(y, 20, None)), note='includes the Kmax host sync')
     report(f'pick_maxima th=2.5 [{N},1,{M}]', y.numel() * 4, timeit(lambda: mask2coords(y, 20, 2.5, 4)), note='includes host sync + scatter')
