@@ -151,6 +151,29 @@ def test_training_matches_reference_golden_f8(dev, precision):
     assert abs(total - float(g['after2_sum'])) < 0.05
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_training_step_at_benched_c5_shape_matches_reference(dev, precision):
+    """One reference training step at the shape bench.py --config C5 times (r = 10, L = 2000, seeded weights), batch 8
+    (tests/golden/make_golden_r2.py training_c5): loss, predictions, every parameter gradient."""
+    from conftest import golden
+    g = golden('f8_training_c5')
+    sd, m, tr = make(dev, 10, 80, seed=3008, precision=precision)
+    frame = torch.from_numpy(synth.synth_echo(8, 2000, seed=3008)).to(dev)
+    gt = torch.from_numpy(g['gt_true']).to(dev)
+    loss, pred = tr.forward_backward(frame, gt)
+    assert abs(float(loss) - float(g['loss'])) < 2e-6 * float(g['loss'])
+    assert relerr(pred.cpu().numpy()[:, 0, ::97], g['pred_stride97']) < 1e-5
+    tol = 2e-4                                              # of max|grad| of the tensor, as in the small-shape tests
+    for name in tr.names:
+        got = tr.g[name].cpu().numpy()
+        gmax = float(g['gmax.' + name])
+        assert abs(float(got.astype(np.float64).sum()) - float(g['gsum.' + name])) < 0.1 * tol * gmax * got.size + 1e-12, name   # whole tensor
+        if 'grad.' + name in g.files:
+            assert np.abs(got - g['grad.' + name]).max() < tol * gmax, name
+        else:
+            assert np.abs(got.reshape(-1)[::53] - g['grad_stride53.' + name]).max() < tol * gmax, name
+
+
 def test_loss_target_matches_reference_blur(dev):
     """The device-built target 20*blur7(onehot)/max against the reference's masks_true_blur (f8)."""
     from conftest import golden

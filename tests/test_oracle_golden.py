@@ -243,3 +243,59 @@ def test_f8_training_oracle_matches_reference_step():
     for k, v in grads.items():
         ref = g['grad.' + k]
         assert np.abs(v - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9, k
+
+
+# ---------------------------------------------------------------- round-2 fixtures (tests/golden/make_golden_r2.py)
+def test_iq2rf_oracle_pinned_by_reference():
+    """f2 row of SURVEY 8f: the oracle's iq2rf against the reference's own ChirpDataset.iq2rf (datasets/chirp_dataset.py:80-91)."""
+    g = golden('f10_iq2rf')
+    for rf in (1, 2.5, 10, 20):
+        got = po.iq2rf(g['iq'], float(g['fc']), float(g['fs']), rf, normalize=False)
+        assert np.abs(got - g[f'rf_{rf}']).max() < 1e-12
+
+
+def test_short_rows_status_is_recorded():
+    import json
+    import os
+    from conftest import GOLDEN
+    st = json.load(open(os.path.join(GOLDEN, 'manifest_r2.json')))['f3_short_status']
+    assert st['40'][0] == st['78'][0] == st['79'][0] == 'RuntimeError' and 'max_pool1d' in st['79'][1]
+    assert st['80'] == ['ok', [2, 1, 320]] and st['82'] == ['ok', [2, 1, 328]]
+    g = golden('f3_short_lengths')
+    sd = load_weights('different-armadillo')
+    for L in (80, 82):
+        y = so.stofnet_forward(sd, g[f'x_L{L}'], 4, 80).numpy()
+        assert np.abs(y - g[f'y_L{L}']).max() < 1e-5 * np.abs(g[f'y_L{L}']).max()
+
+
+def test_long_rows_oracle_envelope_and_gradpeak():
+    g = golden('f9_long_rows')
+    L, rows, seed = 30720, int(g['rows_L30720']), int(g['seed_L30720'])
+    x = synth.synth_echo(rows, L, seed=seed, noise=0.0005, attack=300, tau=3000.0, carrier=0.001)[:, 0]
+    env = po.hilbert_envelope(x)
+    assert np.abs(env[:, ::7] - g['env_L30720']).max() < 1e-5
+    got = po.toa_detect(x, 1e-4, 20, env=env)
+    assert np.array_equal(got[..., :2], g['idx_L30720_th1em4'])
+
+
+def test_gradpeak_1024_oracle_agrees_where_clear_of_the_threshold():
+    """The float64 oracle against the reference's own 1024-row result: identical wherever the smoothed gradient stays
+    clear of the thresholds (a crossing is one float comparison; fp64 and fp32 round it differently)."""
+    g = golden('f9_gradpeak_1024')
+    x = synth.synth_echo(1024, 2000, seed=int(g['seed_rf10']), noise=0.01)[:256, 0]
+    env = po.hilbert_envelope(x)
+    sm = po.smoothed_gradient(env, 5)
+    got = po.toa_detect(x, 1e-3, 10, env=env)
+    exp = g['idx_rf10_th1em3'][:256]
+    k = max(got.shape[1], exp.shape[1])
+    pad = lambda a: np.pad(a, ((0, 0), (0, k - a.shape[1]), (0, 0)))
+    same = (pad(got[..., :2]) == pad(exp)).all(axis=(1, 2))
+    clear = (np.minimum(np.abs(sm - 1e-3), np.abs(sm + 2.5e-4)) > 2e-6 * np.abs(sm).max()).all(axis=1)
+    assert same[clear].all() and clear.mean() > 0.8
+
+
+def test_argmax4096_oracle_subset():
+    g = golden('f1_armadillo_r4_argmax4096')
+    x = synth.synth_echo(4096, 2000, seed=int(g['seed']))[:48]
+    y = so.stofnet_forward(load_weights('different-armadillo'), x, 4, 80).numpy()
+    assert np.array_equal(y[:, 0].argmax(-1), g['indices'][:48])
