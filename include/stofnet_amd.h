@@ -151,6 +151,13 @@ int stof_indices_to_coords(const int32_t* counts, const int32_t* idx, int64_t id
                            int64_t N, int64_t kmax, float upsample_factor,
                            float* coords, void* stream);
 
+/* mask2coords with echo_max < kmax (utils/mask2samples.py:105-107,117-136): coords[N, echo_max] = the echo_max entries
+ * of every row with the largest score amplitude (the reference's zero padding takes part with amplitude scores[row, 0]),
+ * in ascending coordinate order, divided by upsample_factor.  counts / idx as written by stof_pick_maxima.            */
+int stof_reduce_echoes(const float* scores, int64_t N, int64_t M, const int32_t* counts, const int32_t* idx,
+                       int64_t idx_cap, int64_t kmax, int64_t echo_max, float upsample_factor, float* coords,
+                       void* stream);
+
 /* hilbert_transform (utils/hilbert.py:5-21) along the last dim of x[N, n]:
  * writes any of env[N,n] = |v|, re[N,n], im[N,n] that is non-NULL.           */
 size_t stof_hilbert_workspace_bytes(int64_t N, int64_t n);
@@ -263,6 +270,13 @@ int stof_train_upsample_bwd(const float* g, const float* e, float* ge, int64_t N
 int stof_train_loss(const float* pred, const int64_t* gt_idx, int64_t G, const float* taps7, int64_t N, int64_t M,
                     float amplitude, float lambda, float grad_scale, float* target, float* tmax, float* dpred,
                     double* loss, void* stream);
+/* The two halves of stof_train_loss: target[N*M] = blur7(coords2mask(gt)) and its maximum tmax[0]; then the loss and
+ * dpred from (pred, target, tmax).  A batch sharded over ranks MAX-all-reduces tmax in between, because the reference
+ * normalises by the maximum over the WHOLE batch (main.py:230).                                                    */
+int stof_train_loss_target(const int64_t* gt_idx, int64_t G, const float* taps7, int64_t N, int64_t M,
+                           float* target, float* tmax, void* stream);
+int stof_train_loss_grad(const float* pred, float* target, const float* tmax, int64_t N, int64_t M, float amplitude,
+                         float lambda, float grad_scale, float* dpred, double* loss, void* stream);
 /* out = a + b (gradient joins of the residual / long-skip branches, models/stofnet.py:56,62).         */
 int stof_train_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* torch.optim.AdamW step on one flat parameter vector (main.py:179,248).                             */

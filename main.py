@@ -82,7 +82,7 @@ def main(argv=None):
 def train(model, frames, gt, cfg):
     """main.py:199-289 + 403-410 + 423-426 on the HIP training kernels (stofnet_amd/training.py)."""
     import torch.distributed as dist
-    from stofnet_amd.sharding import shard_rows
+    from stofnet_amd.sharding import agree_any, rank_batches
     from stofnet_amd.training import StofNetTrainer
     if gt is None:
         raise RuntimeError('training needs ground-truth onsets (synthetic echoes or a labelled input)')
@@ -97,7 +97,7 @@ def train(model, frames, gt, cfg):
     n_val = max(bs, int(frames.shape[0] * 0.1) // bs * bs)              # held-out tail for early stopping
     tr_x, tr_gt = frames[:-n_val], gt[:-n_val]
     va_x, va_gt = frames[-n_val:], gt[-n_val:]
-    lo, hi = shard_rows(tr_x.shape[0] // bs, rank, world)                # whole batches per rank
+    mine = rank_batches(tr_x.shape[0] // bs, rank, world)                # the same number of steps on every rank
     best, bad, history = float('inf'), 0, []
 
     def gt_true_of(g):
@@ -109,7 +109,7 @@ def train(model, frames, gt, cfg):
         tr.set_lr_cosine(e, int(cfg.epochs), float(cfg.lr))              # CosineAnnealingLR stepped per epoch
         model.train()
         tot = 0.0
-        for b in range(lo, hi):
+        for b in mine:
             sl = slice(b * bs, (b + 1) * bs)
             loss, _ = tr.train_step(torch.from_numpy(tr_x[sl]).to(cfg.device), gt_true_of(tr_gt[sl]))
             tot += float(loss)
@@ -119,15 +119,15 @@ def train(model, frames, gt, cfg):
             for b0 in range(0, va_x.shape[0] - bs + 1, bs):
                 pred = model(torch.from_numpy(va_x[b0:b0 + bs]).to(cfg.device))
                 val += float(tr.loss(pred, gt_true_of(va_gt[b0:b0 + bs])))
-        history.append({'epoch': e, 'lr': tr.lr, 'train_loss': tot / max(hi - lo, 1), 'val_loss': val})
+        history.append({'epoch': e, 'lr': tr.lr, 'train_loss': tot / max(len(mine), 1), 'val_loss': val})
         if rank == 0:
             print(json.dumps(history[-1]))
         if val < best - float(cfg.delta):                                # EarlyStopping (utils/early_stop.py)
             best, bad = val, 0
         else:
             bad += 1
-            if bad >= int(cfg.patience):
-                break
+        if agree_any(bad >= int(cfg.patience), device=cfg.device):       # every rank leaves at the same epoch
+            break
     if rank == 0 and cfg.ckpt_dir:
         ckpt_dir = Path(cfg.ckpt_dir) if os.path.isabs(str(cfg.ckpt_dir)) else script_path / cfg.ckpt_dir
         ckpt_dir.mkdir(exist_ok=True)

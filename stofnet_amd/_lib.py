@@ -63,6 +63,8 @@ _SIGNATURES = {
                                     _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
     'stof_indices_to_coords': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float,
                                           _c.c_void_p, _c.c_void_p]),
+    'stof_reduce_echoes': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
+                                      _c.c_int64, _c.c_float, _c.c_void_p, _c.c_void_p]),
     'stof_hilbert_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int64]),
     'stof_hilbert': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                 _c.c_void_p, _c.c_size_t, _c.c_void_p]),
@@ -93,6 +95,8 @@ _SIGNATURES = {
     'stof_train_upsample_add': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p]),
     'stof_train_upsample_bwd': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p]),
     'stof_train_loss': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'stof_train_loss_target': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'stof_train_loss_grad': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'stof_train_add': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
     'stof_train_adamw': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_int64, _c.c_void_p]),
 }

@@ -236,7 +236,74 @@ __global__ __launch_bounds__(256) void indices_to_coords_kernel(const int* __res
     coords[i] = v / r;                 // IEEE division, as torch's coords /= upsample_factor
 }
 
+// mask2coords' echo_max reduction (utils/mask2samples.py:105-107 -> reduce_echoes :117-132, get_amplitudes :135-136)
+// for rows with more than echo_max detections batch-wide: every row's kmax entries (its detections, then the
+// reference's zero padding, whose "amplitude" is scores[row, 0]) are ranked by amplitude, the echo_max largest kept
+// (ties: the earlier entry) and written in ascending coordinate order, i.e. kept padding first, then the kept
+// detections in time order; coordinates are divided by the upsample factor (:112).  One wavefront per row.
+__global__ __launch_bounds__(256) void reduce_echoes_kernel(const float* __restrict__ scores, long long M,
+                                                            const int* __restrict__ counts, const int* __restrict__ idx,
+                                                            long long idx_cap, long long N, int kmax, int k, float r,
+                                                            float* __restrict__ coords) {
+    const int lane = threadIdx.x & 63;
+    const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float* s = scores + row * M;
+    const int cnt = min(counts[row], kmax);
+    const int nt = (kmax + 63) / 64;                       // entries lane + 64 t, t < nt <= 64 (kmax <= 4096)
+    auto coord_of = [&](int e) { return e < cnt ? idx[row * idx_cap + e] : 0; };
+    unsigned long long taken = 0;
+    for (int round = 0; round < k; ++round) {
+        float best = -INFINITY;
+        int best_e = 0x7fffffff;
+        for (int t = 0; t < nt; ++t) {
+            const int e = lane + 64 * t;
+            if (e < kmax && !((taken >> t) & 1ull)) {
+                const float a = s[coord_of(e)];
+                if (a > best || best_e == 0x7fffffff) { best = a; best_e = e; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oe = __shfl_xor(best_e, o);
+            if (oe != 0x7fffffff && (best_e == 0x7fffffff || ob > best || (ob == best && oe < best_e))) { best = ob; best_e = oe; }
+        }
+        if (best_e != 0x7fffffff && (best_e & 63) == lane) taken |= 1ull << (best_e >> 6);
+    }
+    // kept padding entries (coordinate 0) sort in front of the kept detections
+    int npad = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int e = lane + 64 * t;
+        npad += __builtin_popcountll(__ballot(((taken >> t) & 1ull) && e >= cnt));
+    }
+    float* out = coords + row * (long long)k;
+    for (int p = lane; p < npad; p += 64) out[p] = 0.f / r;
+    int pos = npad;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int t = 0; t < nt; ++t) {
+        const int e = lane + 64 * t;
+        const bool sel = ((taken >> t) & 1ull) && e < cnt;
+        const unsigned long long sm = __ballot(sel);
+        if (sel) out[pos + __builtin_popcountll(sm & lt_mask)] = (float)coord_of(e) / r;
+        pos += __builtin_popcountll(sm);
+    }
+}
+
 }  // namespace
+
+extern "C" int stof_reduce_echoes(const float* scores, int64_t N, int64_t M, const int32_t* counts, const int32_t* idx,
+                                  int64_t idx_cap, int64_t kmax, int64_t echo_max, float upsample_factor, float* coords,
+                                  void* stream) {
+    if (!scores || !counts || !idx || !coords || N < 0 || M < 1 || kmax < 1 || echo_max < 1 || echo_max >= kmax || kmax > idx_cap)
+        return STOF_ERR_BAD_ARG;
+    if (N == 0) return STOF_OK;
+    if (kmax > 4096 || N > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(reduce_echoes_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       scores, (long long)M, counts, idx, (long long)idx_cap, (long long)N, (int)kmax, (int)echo_max,
+                       upsample_factor, coords);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
 
 extern "C" int stof_sample_shuffle(const float* in, float* out, int64_t N, int64_t C_in, int64_t W, int32_t r,
                                    void* stream) {

@@ -1021,25 +1021,44 @@ extern "C" int stof_train_upsample_bwd(const float* g, const float* e, float* ge
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
-// scratch: tmax[1] float (zeroed here), target[N*M]; loss[1] double (zeroed here)
-extern "C" int stof_train_loss(const float* pred, const int64_t* gt_idx, int64_t G, const float* taps7, int64_t N, int64_t M,
-                               float amplitude, float lambda, float grad_scale, float* target, float* tmax, float* dpred,
-                               double* loss, void* stream) {
+// The loss of main.py:228-232 in two halves, so that a batch sharded over ranks can MAX-all-reduce the maximum of the
+// blurred target in between (`masks_true_blur /= masks_true_blur.max()` is a maximum over the WHOLE batch, main.py:230).
+extern "C" int stof_train_loss_target(const int64_t* gt_idx, int64_t G, const float* taps7, int64_t N, int64_t M,
+                                      float* target, float* tmax, void* stream) {
     if (N < 0 || M < 0 || G < 0) return STOF_ERR_BAD_ARG;
     if (N * M == 0) return STOF_OK;
-    if (!pred || !gt_idx || !taps7 || !target || !tmax || !dpred || !loss) return STOF_ERR_BAD_ARG;
+    if (!gt_idx || !taps7 || !target || !tmax) return STOF_ERR_BAD_ARG;
     if ((size_t)M * sizeof(float) > 160 * 1024) return STOF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(tmax, 0, sizeof(float), s) != hipSuccess || hipMemsetAsync(loss, 0, sizeof(double), s) != hipSuccess)
-        return STOF_ERR_HIP;
+    if (hipMemsetAsync(tmax, 0, sizeof(float), s) != hipSuccess) return STOF_ERR_HIP;
     static stof::LdsLimitOnce loss_lds;
     if (int st = loss_lds.ensure(reinterpret_cast<const void*>(&loss_target_kernel), 160 * 1024)) return st;
     hipLaunchKernelGGL(loss_target_kernel, dim3((unsigned)N), dim3(256), (size_t)M * sizeof(float), s,
                        reinterpret_cast<const long long*>(gt_idx), (int)G, taps7, target, (int)N, (int)M, tmax);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_loss_grad(const float* pred, float* target, const float* tmax, int64_t N, int64_t M, float amplitude,
+                                    float lambda, float grad_scale, float* dpred, double* loss, void* stream) {
+    if (N < 0 || M < 0) return STOF_ERR_BAD_ARG;
+    if (N * M == 0) return STOF_OK;
+    if (!pred || !target || !tmax || !dpred || !loss) return STOF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(loss, 0, sizeof(double), s) != hipSuccess) return STOF_ERR_HIP;
     const unsigned lblocks = blocks_for(N * M) < 2048u ? blocks_for(N * M) : 2048u;   // one double atomic per block
     hipLaunchKernelGGL(loss_grad_kernel, dim3(lblocks), dim3(256), 0, s, pred, target, tmax, amplitude, lambda,
                        (long long)(N * M), grad_scale, dpred, loss);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+// single-process form: both halves back to back
+extern "C" int stof_train_loss(const float* pred, const int64_t* gt_idx, int64_t G, const float* taps7, int64_t N, int64_t M,
+                               float amplitude, float lambda, float grad_scale, float* target, float* tmax, float* dpred,
+                               double* loss, void* stream) {
+    if (!pred || !dpred || !loss) return (N * M == 0 && N >= 0 && M >= 0 && G >= 0) ? STOF_OK : STOF_ERR_BAD_ARG;
+    const int st = stof_train_loss_target(gt_idx, G, taps7, N, M, target, tmax, stream);
+    if (st != STOF_OK) return st;
+    return stof_train_loss_grad(pred, target, tmax, N, M, amplitude, lambda, grad_scale, dpred, loss, stream);
 }
 
 extern "C" int stof_train_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -1,9 +1,7 @@
 """mask2coords on the gfx950 picker kernels (mirrors utils/mask2samples.py:26-34,81-148).
 
-`get_maxima_positions` and the padded scatter run on the device; the only host
-sync is the one the reference has too (`int(max(counts))`, :93).  The rarely used
-`echo_max` reduction (:105-110,117-132) is a few tensor ops on the tiny [N,Kmax]
-result, as in the reference.
+`get_maxima_positions`, the padded scatter and the `echo_max` reduction run on the
+device; the only host sync is the one the reference has too (`int(max(counts))`, :93).
 """
 import torch
 
@@ -14,10 +12,10 @@ _IDX_CAP = 32            # detections per row kept by the first pass; larger row
 
 def _pick(scores: torch.Tensor, window_size: int, threshold, cap: int, counts=None, idx=None):
     _lib.require_device(scores, 'scores')
-    if scores.dim() != 3 or scores.shape[1] != 1:
-        raise RuntimeError('mask2coords expects scores of shape [N, 1, M] (utils/mask2samples.py:32)')
+    if scores.dim() != 3:
+        raise RuntimeError('expected scores of shape [N, C, M]')
     s = scores.detach().contiguous().float()
-    n, _, m = s.shape
+    n, m = s.shape[0] * s.shape[1], s.shape[2]          # NMS and thresholding are per (batch, channel) row
     if counts is None:
         counts = torch.empty((n,), dtype=torch.int32, device=s.device)
     if idx is None:
@@ -52,14 +50,58 @@ def pick_async(scores, window_size, threshold=None, cap=_IDX_CAP, counts=None, i
 
 
 def get_maxima_positions(scores, window_size, threshold=None):
-    """int64 [K, 2] (row, time), row-major (utils/mask2samples.py:26-34)."""
+    """utils/mask2samples.py:26-34: int64 [K, 2] (row, time) for scores [N, 1, M] (the reference squeezes dim 1, :32),
+    [K, 3] (batch, channel, time) for C > 1; row-major like torch.nonzero."""
     s, counts, idx, kmax = _pick_all(scores, window_size, threshold)
+    c = s.shape[1]
     if kmax == 0:
-        return torch.zeros((0, 2), dtype=torch.long, device=s.device)
+        return torch.zeros((0, 2 if c == 1 else 3), dtype=torch.long, device=s.device)
     ar = torch.arange(kmax, device=s.device)[None, :]
     mask = ar < counts[:, None]
-    rows = torch.arange(s.shape[0], device=s.device)[:, None].expand(-1, kmax)[mask]
-    return torch.stack([rows.long(), idx[:, :kmax][mask].long()], dim=1)
+    rows = torch.arange(counts.shape[0], device=s.device)[:, None].expand(-1, kmax)[mask].long()
+    t = idx[:, :kmax][mask].long()
+    if c == 1:
+        return torch.stack([rows, t], dim=1)
+    return torch.stack([rows // c, rows % c, t], dim=1)
+
+
+def mask2nested_list(scores, window_size, threshold=None, upsample_factor=1):
+    """utils/mask2samples.py:37-51 ('caution: computationally expensive'): nested [batch][channel] lists of numpy
+    arrays of detections / upsample_factor.  The detection runs on the picker kernel; the list building is the
+    reference's host loop over the index tensor, including its behaviour for [N, 1, M] scores, where column 1 of the
+    (squeezed) index tensor is the TIME and the inner loop therefore runs over time indices."""
+    indices = get_maxima_positions(scores, window_size, threshold).cpu()
+    nested_list = []
+    for bidx in range(int(indices[:, 0].max()) + 1):
+        helper_list = []
+        for cidx in range(int(indices[:, 1].max()) + 1):
+            samples = indices[(indices[:, 0] == bidx) & (indices[:, 1] == cidx), -1] / upsample_factor
+            helper_list.append(samples.numpy())
+        nested_list.append(helper_list)
+    return nested_list
+
+
+def batch_mask2coords(scores, window_size, threshold=None, upsample_factor=1):
+    """utils/mask2samples.py:54-78 for scores [B, C, M] with C > 1: float coords [b_max, c_max, K] where b_max / c_max
+    are the largest batch / channel index WITH a detection + 1 and -- as in the reference, whose fill index counts the
+    occupied (batch, channel) pairs (:71, enumerate over torch.unique) -- the i-th occupied pair fills row i of the
+    flattened [b_max * c_max, K] tensor, so pairs without detections shift later ones up."""
+    indices = get_maxima_positions(scores, window_size, threshold)
+    if indices.numel() == 0:                              # :58-59
+        return torch.zeros((scores.shape[0], scores.shape[1], 1), device=scores.device)
+    if indices.shape[1] != 3:
+        raise IndexError('index 2 is out of bounds for dimension 1 with size 2')      # the reference's indices[:, 2] (:64)
+    b_max = int(indices[:, 0].max()) + 1
+    c_max = int(indices[:, 1].max()) + 1
+    samples = indices[:, 2].float() / upsample_factor
+    flat2d = indices[:, 0] * c_max + indices[:, 1]
+    _, inverse, counts = torch.unique(flat2d, return_inverse=True, return_counts=True)
+    kmax = int(counts.max())
+    start = torch.cumsum(counts, 0) - counts              # first detection of every occupied pair (row-major order)
+    within = torch.arange(indices.shape[0], device=indices.device) - start[inverse]
+    coords = torch.zeros((b_max, c_max, kmax), device=scores.device)
+    coords.view(-1)[inverse * kmax + within] = samples
+    return coords
 
 
 def onset_indices(scores, window_size, threshold=None):
@@ -69,28 +111,32 @@ def onset_indices(scores, window_size, threshold=None):
 
 
 def mask2coords(scores, window_size, threshold=None, upsample_factor=1, echo_max=None):
+    """utils/mask2samples.py:81-114 on the picker kernels; the one host sync is the reference's own (`int(max(counts))`)."""
     s, counts, idx, kmax = _pick_all(scores, window_size, threshold)
+    if s.shape[1] != 1:
+        raise RuntimeError('mask2coords expects scores of shape [N, 1, M] (utils/mask2samples.py:32)')
     n = s.shape[0]
     if kmax == 0:                                        # utils/mask2samples.py:87-88
         return torch.zeros((n, s.shape[1], 1), device=s.device)
-    coords = torch.empty((n, kmax), dtype=torch.float32, device=s.device)
-    reduce = bool(echo_max) and echo_max < kmax
+    lib = _lib.lib()
     with torch.cuda.device(s.device):
-        _lib.check(_lib.lib().stof_indices_to_coords(_lib.ptr(counts), _lib.ptr(idx), idx.shape[1], n, kmax,
-                                                     1.0 if reduce else float(upsample_factor),
-                                                     _lib.ptr(coords), _lib.stream_ptr(s.device)),
-                   'stof_indices_to_coords')
-    if reduce:                                           # :105-107 -> reduce_echoes :117-132
-        amplitudes = get_amplitudes(s, coords)
-        coords = reduce_echoes(torch.dstack([coords, amplitudes]), echo_max=echo_max)[..., 0]
-        coords = coords / upsample_factor
-    elif echo_max and echo_max > kmax:                   # :108-110
-        pad = torch.zeros(n, int(echo_max) - kmax, device=coords.device, dtype=coords.dtype)
-        coords = torch.cat([coords, pad], dim=-1)
+        if echo_max and echo_max < kmax:                 # :105-107 -> reduce_echoes :117-132 on the device
+            k = int(echo_max)
+            coords = torch.empty((n, k), dtype=torch.float32, device=s.device)
+            _lib.check(lib.stof_reduce_echoes(_lib.ptr(s), n, s.shape[2], _lib.ptr(counts), _lib.ptr(idx), idx.shape[1], kmax,
+                                              k, float(upsample_factor), _lib.ptr(coords), _lib.stream_ptr(s.device)),
+                       'stof_reduce_echoes')
+            return coords
+        width = int(echo_max) if (echo_max and echo_max > kmax) else kmax      # :108-110: zero padding up to echo_max
+        coords = torch.empty((n, width), dtype=torch.float32, device=s.device)
+        _lib.check(lib.stof_indices_to_coords(_lib.ptr(counts), _lib.ptr(idx), idx.shape[1], n, width, float(upsample_factor),
+                                              _lib.ptr(coords), _lib.stream_ptr(s.device)), 'stof_indices_to_coords')
     return coords
 
 
 def reduce_echoes(samples_and_amps, echo_max=100):
+    """utils/mask2samples.py:117-132 for callers that hold a [N, K, C] tensor already (mask2coords itself uses the
+    stof_reduce_echoes kernel); a few tensor ops on a tiny result."""
     echo_num = samples_and_amps.shape[1]
     channel_num = samples_and_amps.shape[-1]
     echoes = samples_and_amps

@@ -10,7 +10,11 @@ torch.distributed only (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" 
                            to the batch-wide Kmax, utils/mask2samples.py:93) + one all_gather of
                            the [rows, Kmax] int32 onset indices (4*K bytes per waveform)
   * global_grad_moments -- GradPeak's default threshold uses the std of the WHOLE batch
-                           (models/gradpeak.py:18, Q7): all-reduce (sum, sum of squares, count)
+                           (models/gradpeak.py:18, Q7): all-reduce (sum, sum of squares, count); gradpeak.py does this
+                           on the device tensor when torch.distributed is initialised
+  * rank_batches        -- DDP training: every rank runs the SAME number of steps per epoch (each step is one
+                           gradient all-reduce; unequal counts would pair collectives of different epochs and hang)
+  * agree_any           -- a boolean decision (early stopping) taken identically on every rank
 """
 from __future__ import annotations
 
@@ -59,3 +63,23 @@ def global_grad_moments(s1: float, s2: float, count: int, device=None, group=Non
     t = torch.tensor([s1, s2, float(count)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t[0]), float(t[1]), int(round(float(t[2])))
+
+
+def rank_batches(n_batches: int, rank: int, world: int) -> list[int]:
+    """Global batch indices of `rank` for one epoch: rank, rank + world, ... over the first
+    (n_batches // world) * world batches.  Every rank gets exactly n_batches // world steps -- the remainder
+    (< world batches) is dropped, like DataLoader(drop_last=True) drops a ragged tail -- so the per-step gradient
+    all-reduces line up across ranks."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError('bad rank/world')
+    steps = n_batches // world
+    return [rank + k * world for k in range(steps)]
+
+
+def agree_any(flag: bool, device=None, group=None) -> bool:
+    """True on every rank iff `flag` is true on at least one (MAX all-reduce of one byte-sized int)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t.item()))

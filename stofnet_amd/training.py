@@ -45,6 +45,7 @@ class StofNetTrainer:
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
         self.lam, self.amp = float(lambda_value), float(mask_amplitude)
         self.group = process_group
+        self.target_max_hook = None      # tests: stands in for the MAX all-reduce of the blurred-target maximum
         self.step_count = 0
         self._gscale = 1.0
         params = list(model.named_parameters())
@@ -156,9 +157,7 @@ class StofNetTrainer:
             # loss scaling by a power of two (exact): dloss/dpred ~ 2*diff/(N*M) would sit in the fp16 subnormal range of
             # the f16x3 data-gradient convolutions; the weight-gradient kernels undo it with 1/scale
             self._gscale = 2.0 ** math.floor(math.log2(max(n * L * r / 8.0, 1.0)))
-            _lib.check(lib.stof_train_loss(_lib.ptr(pred), _lib.ptr(gt), gt.shape[1], _lib.ptr(self.taps), n, L * r, self.amp,
-                                           self.lam, self._gscale, _lib.ptr(target), _lib.ptr(tmax), _lib.ptr(dpred),
-                                           _lib.ptr(loss), st), 'stof_train_loss')
+            self._loss_kernels(pred, gt, n, L * r, self._gscale, target, tmax, dpred, loss)
             # ---------------- backward
             dz = dpred.view(n, L, r)
             self._wgrad(x6, dz, 'conv_last', 64, r, 3)
@@ -201,10 +200,20 @@ class StofNetTrainer:
         tmax = torch.empty(1, dtype=torch.float32, device=self.dev)
         loss = torch.empty(1, dtype=torch.float64, device=self.dev)
         with torch.cuda.device(self.dev):
-            _lib.check(_lib.lib().stof_train_loss(_lib.ptr(pred), _lib.ptr(gt), gt.shape[1], _lib.ptr(self.taps), n, m, self.amp,
-                                                  self.lam, 1.0, _lib.ptr(target), _lib.ptr(tmax), _lib.ptr(dpred),
-                                                  _lib.ptr(loss), self._st()), 'stof_train_loss')
+            self._loss_kernels(pred, gt, n, m, 1.0, target, tmax, dpred, loss, sharded=False)
         return loss[0]
+
+    def _loss_kernels(self, pred, gt, n, m, gscale, target, tmax, dpred, loss, sharded=True):
+        """main.py:228-232.  The blurred target is divided by its maximum over the WHOLE batch (main.py:230): when the
+        batch is sharded over ranks the local maxima are MAX-all-reduced between the two kernels (a shard whose echoes
+        overlap has a larger maximum than one whose echoes do not)."""
+        lib = _lib.lib()
+        _lib.check(lib.stof_train_loss_target(_lib.ptr(gt), gt.shape[1], _lib.ptr(self.taps), n, m, _lib.ptr(target),
+                                              _lib.ptr(tmax), self._st()), 'stof_train_loss_target')
+        if sharded:
+            (self.target_max_hook or (lambda t: allreduce_max_(t, self.group)))(tmax)
+        _lib.check(lib.stof_train_loss_grad(_lib.ptr(pred), _lib.ptr(target), _lib.ptr(tmax), n, m, self.amp, self.lam,
+                                            float(gscale), _lib.ptr(dpred), _lib.ptr(loss), self._st()), 'stof_train_loss_grad')
 
     def allreduce_grads(self):
         """DDP semantics: average the flat gradient bucket over the process group (RCCL over xGMI on the
@@ -230,6 +239,13 @@ class StofNetTrainer:
     def set_lr_cosine(self, epoch, epochs, base_lr):
         """CosineAnnealingLR(optimizer, epochs) stepped once per epoch (main.py:180,288)."""
         self.lr = 0.5 * base_lr * (1.0 + math.cos(math.pi * epoch / epochs))
+
+
+def allreduce_max_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place MAX all-reduce (the batch-global maximum of the blurred target, main.py:230)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
 
 
 def allreduce_mean_(flat_grad: torch.Tensor, group=None) -> torch.Tensor:

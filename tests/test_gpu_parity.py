@@ -328,6 +328,21 @@ def test_picker_on_network_maps(dev):
     assert np.array_equal(mask2coords(y, 20, 0.015, 4, 40).cpu().numpy(), g['coords_th_echo40'])
 
 
+def test_batch_mask2coords_and_nested_list_vs_reference(dev):
+    """utils/mask2samples.py:37-79 (the two helpers main.py:19 imports besides mask2coords) and the echo_max reduction
+    kernel, against the reference's outputs (make_golden_r2.py batch_coords)."""
+    from utils.mask2samples import batch_mask2coords, mask2coords, mask2nested_list      # the drop-in module path
+    g = golden('f4_batch_coords')
+    s = torch.from_numpy(g['scores']).to(dev)
+    assert np.array_equal(batch_mask2coords(s, 20, 1.0, 4).cpu().numpy(), g['coords'])
+    nested = mask2nested_list(s, 20, 1.0, 4)
+    assert np.array_equal(np.array([[len(c) for c in b] for b in nested], np.int64), g['nested_len'])
+    assert np.array_equal(np.concatenate([np.asarray(c, np.float32) for b in nested for c in b]), g['nested_val'])
+    s1 = torch.from_numpy(g['scores1']).to(dev)
+    for em in (2, 3):
+        assert np.array_equal(mask2coords(s1, 20, 0.8, 4, em).cpu().numpy(), g[f'm2c_em{em}'])
+
+
 @pytest.mark.parametrize('M,win,th', [(1000, 20, None), (1025, 20, 0.3), (3000, 7, 0.0), (5000, 1, 1.0),
                                       (40000, 20, None), (17, 20, None), (4097, 128, 0.5)])
 def test_picker_random_vs_oracle(dev, M, win, th):

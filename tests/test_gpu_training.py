@@ -232,3 +232,32 @@ def test_ddp_mean_of_shard_gradients_equals_full_batch_gradient(dev):
         grads.append(tr.flat_grad.cpu().numpy().astype(np.float64))
     mean = 0.5 * (grads[0] + grads[1])
     assert np.abs(mean - grads[2]).max() < 1e-5 * np.abs(grads[2]).max()
+
+
+def test_ddp_shards_with_different_target_maxima_match_full_batch(dev):
+    """The reference divides the blurred target by its maximum over the WHOLE batch (main.py:230).  Shard 0 holds two
+    overlapping echoes (a larger local maximum than shard 1): with the maxima MAX-reduced between the two loss kernels
+    (here through the trainer's hook, on the node through RCCL) the mean of the shard gradients is the full-batch
+    gradient; with local maxima it is not."""
+    r, sgs, L = 4, 80, 320
+    x = synth.synth_echo(4, L, seed=21)
+    gt = np.array([[[200, 202]], [[300, 302]], [[100, 400]], [[50, 500]]], dtype=np.int64)
+    _, _, full = make(dev, r, sgs, seed=8)
+    seen = {}
+    full.target_max_hook = lambda t: seen.__setitem__('global', float(t))
+    full.forward_backward(torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev))
+    g_full = full.flat_grad.cpu().numpy().astype(np.float64)
+    local, fixed = [], []
+    for rows in (slice(0, 2), slice(2, 4)):
+        for mode, store in (('local', local), ('global', fixed)):
+            _, _, tr = make(dev, r, sgs, seed=8)
+            if mode == 'global':
+                tr.target_max_hook = lambda t: t.fill_(seen['global'])          # what the MAX all-reduce delivers
+            else:
+                tr.target_max_hook = lambda t: seen.__setitem__(f'local{rows.start}', float(t))
+            tr.forward_backward(torch.from_numpy(x[rows]).to(dev), torch.from_numpy(gt[rows]).to(dev))
+            store.append(tr.flat_grad.cpu().numpy().astype(np.float64))
+    assert seen['local0'] > seen['local2'] + 0.05 and abs(seen['global'] - seen['local0']) < 1e-7
+    scale = np.abs(g_full).max()
+    assert np.abs(0.5 * (fixed[0] + fixed[1]) - g_full).max() < 1e-5 * scale
+    assert np.abs(0.5 * (local[0] + local[1]) - g_full).max() > 1e-3 * scale      # the bug this guards against
