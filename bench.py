@@ -457,6 +457,23 @@ def infer_bench(args):
         idx = torch.where(ar < counts[:, None], idx, torch.zeros((), dtype=torch.int32, device=dev)).contiguous()
         extras['picker_argmax_ms'] = round(pick_ms, 3)
         extras['waveforms_per_s_forward_plus_picker'] = round(d.world * rows / (dt / args.steps + pick_ms * 1e-3), 1)
+    # the arg-max picker fused into the sweep (stof_forward_onsets): picker-only output, the map never reaches HBM
+    if args.precision != 'fp32' and R <= 16:
+        def fused_pass():
+            for c in range(nchunk):
+                model.forward_onsets(x if nchunk == 1 else x[c * chunk:(c + 1) * chunk], 20)
+        fused_pass()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            fused_pass()
+        torch.cuda.synchronize()
+        fdt = (time.perf_counter() - t1) / 3
+        fc, fi = model.forward_onsets(x[:chunk], 20)
+        rc, ri = onset_indices(model(x[:chunk]), 20, None)
+        extras['fused_argmax_onsets'] = {'ms_per_step': round(fdt * 1e3, 3), 'waveforms_per_s': round(d.world * rows / fdt, 1),
+                                         'identical_to_map_plus_picker': bool(torch.equal(fc, rc) and torch.equal(fi, ri)),
+                                         'note': 'StofNet.forward_onsets: output = onset indices only (includes the Kmax host sync)'}
     extras['index_gather_ms'] = None
     if d.dist is not None:
         gather_onsets(counts, idx)                       # warm-up (communicator set-up)

@@ -112,6 +112,18 @@ int stof_forward_auto(const stof_net_desc* desc, const void* packed_f16x3_dev, c
                       const float* x, float* y, int64_t N, int64_t L, void* workspace, size_t workspace_bytes,
                       void* stream, int32_t* status_dev, void* const* events);
 
+/* StofNet.forward with get_maxima_positions in arg-max mode (utils/mask2samples.py:26-34, threshold = None) fused into
+ * conv_last's epilogue (main.py:314 -> 320 for th = Null): per row the positions of the maximum of the NMS output, ties
+ * and the constant-negative-row rule exactly as stof_pick_maxima reports them, WITHOUT the [N, 1, L*r] map going
+ * through HBM -- `y` may be NULL (picker-only consumers: 4 bytes per onset instead of 4*L*r per waveform) or receive
+ * the map as stof_forward would write it.  counts / idx / idx_cap as in stof_pick_maxima.  STOF_PREC_F16X3 and
+ * upsample_factor <= 16 only (else STOF_ERR_UNSUPPORTED: use stof_forward + stof_pick_maxima); status_dev as in
+ * stof_forward_checked (may be NULL).                                                                              */
+size_t stof_forward_onsets_workspace_bytes(const stof_net_desc* desc, int64_t N, int64_t L);
+int stof_forward_onsets(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y, int64_t N,
+                        int64_t L, int32_t window_size, int32_t* counts, int32_t* idx, int64_t idx_cap,
+                        void* workspace, size_t workspace_bytes, void* stream, int32_t* status_dev);
+
 /* Same as stof_forward, with instrumentation for bench.py: `events` is an array of
  * STOF_FORWARD_EVENTS hipEvent_t recorded on `stream` before the first kernel and after each
  * kernel of the first sub-batch (SemiGlobalBlock contract+pool, expand, body sweep), so the

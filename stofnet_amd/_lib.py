@@ -51,6 +51,10 @@ _SIGNATURES = {
     'stof_forward_events': (_c.c_int, [_c.POINTER(NetDesc), _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                        _c.c_int64, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.POINTER(_c.c_void_p),
                                        _c.c_void_p]),
+    'stof_forward_onsets_workspace_bytes': (_c.c_size_t, [_c.POINTER(NetDesc), _c.c_int64, _c.c_int64]),
+    'stof_forward_onsets': (_c.c_int, [_c.POINTER(NetDesc), _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
+                                       _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_size_t, _c.c_void_p,
+                                       _c.c_void_p]),
     'stof_forward_auto': (_c.c_int, [_c.POINTER(NetDesc), _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                      _c.c_int64, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
                                      _c.POINTER(_c.c_void_p)]),

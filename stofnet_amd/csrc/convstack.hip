@@ -140,6 +140,18 @@ __device__ __forceinline__ unsigned long long stamp() {
 // ----------------------------------------------------------------------------------
 // body sweep
 // ----------------------------------------------------------------------------------
+// What a 16-row tile of the network output (16 time rows x r <= 16 channels = 16 r consecutive-ish map positions of one
+// waveform) contributes to get_maxima_positions in arg-max mode (utils/mask2samples.py:14-34): its maximum, its
+// minimum and the exact set of positions that equal its maximum -- bit (e, lane) of eq[e] is output channel
+// 4 (lane >> 4) + e of time row tw_base + (lane & 15), i.e. map position (tw_base + (lane & 15)) * r + 4 (lane >> 4) + e.
+struct OnsetPartial {
+    int written;                  // 0 = slot not used
+    int tw_base;
+    float m, lo;
+    unsigned long long eq[4];
+};
+static_assert(sizeof(OnsetPartial) == 48, "OnsetPartial is three 16-byte stores");
+
 struct BodyParams {
     const float* x;        // [N][L]
     const float* sgb;      // [N][P][64] or nullptr
@@ -156,6 +168,10 @@ struct BodyParams {
     unsigned long long* stamps;   // diagnostic builds (-DSTOF_STAMPS) only: [wg][wave][8] cycle sums
     int* status;                  // optional: bit 0 set if a non-finite output was produced (f16x3 range overflow)
     const int* run_if;            // optional: the whole launch returns at once while *run_if == 0 ('auto' precision re-run)
+    // fused arg-max picker (stof_forward_onsets): every 16-row tile of conv_last's output leaves one OnsetPartial per
+    // (virtual) waveform it touches; onsets_finalize_kernel turns them into counts / indices.  y may then be nullptr.
+    OnsetPartial* onset_ws;       // [N][onset_slots] (this sub-batch), zeroed by the host side before the launch
+    int onset_slots, onset_seg_slots;
 };
 
 template <int S, int RING, int RAWRING>
@@ -631,7 +647,42 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                                         (tk >= p.halo) && (tk < p.halo + p.seg_len);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) bad = bad || !(fabsf(a16[k][e]) <= 3.0e38f);
-                        if (!ok || 4 * q4 >= r) continue;
+                        if (p.onset_ws != nullptr) {
+                            // fused arg-max picker: per (virtual) waveform of this tile -- at most two, the tile is 16
+                            // consecutive stream rows -- its max / min and the positions equal to the max
+                            const bool lane_ok = ok && 4 * q4 < r;
+                            float lm = -INFINITY, ll = INFINITY;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (lane_ok && 4 * q4 + e < r) { lm = fmaxf(lm, a16[k][e]); ll = fminf(ll, a16[k][e]); }
+                            const int nv = n0 + nk;
+                            const int nvA = __shfl(nv, 0), nvB = __shfl(nv, 15);
+                            for (int pass = 0; pass < 2; ++pass) {
+                                const int nvX = pass ? nvB : nvA;
+                                if (pass && nvB == nvA) break;
+                                const bool mine = lane_ok && nv == nvX;
+                                const unsigned long long mm = __ballot(mine) & 0xffffull;      // rows of this waveform (q4 = 0 lanes)
+                                if (mm == 0) continue;
+                                float m = mine ? lm : -INFINITY, lo = mine ? ll : INFINITY;
+#pragma unroll
+                                for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); lo = fminf(lo, __shfl_xor(lo, o)); }
+                                const int jf = __builtin_ctzll(mm);
+                                const int tw_base = __shfl(tw - j16, jf);
+                                const int nwX = __shfl(nw, jf);
+                                const int seg = nvX & seg_mask;
+                                const int slot = seg * p.onset_seg_slots + (tw_base + jf - seg * p.seg_len + 15) / 16;
+                                unsigned long long eq[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) eq[e] = __ballot(mine && 4 * q4 + e < r && a16[k][e] == m);
+                                if (lane == 0) {
+                                    uint4* dst = reinterpret_cast<uint4*>(p.onset_ws + (size_t)nwX * p.onset_slots + slot);
+                                    dst[0] = make_uint4(1u, (unsigned)tw_base, __float_as_uint(m), __float_as_uint(lo));
+                                    dst[1] = make_uint4((unsigned)eq[0], (unsigned)(eq[0] >> 32), (unsigned)eq[1], (unsigned)(eq[1] >> 32));
+                                    dst[2] = make_uint4((unsigned)eq[2], (unsigned)(eq[2] >> 32), (unsigned)eq[3], (unsigned)(eq[3] >> 32));
+                                }
+                            }
+                        }
+                        if (!ok || 4 * q4 >= r || p.y == nullptr) continue;
                         float* const orow = p.y + ((size_t)nw * Ltrue + tw) * r + 4 * q4;
                         if ((r & 3) == 0) {
                             st4(orow, make_float4(a16[k][0], a16[k][1], a16[k][2], a16[k][3]));
@@ -934,7 +985,58 @@ __global__ __launch_bounds__(256, SGB_WAVES_PER_SIMD) void sgb_contract_pool_ker
     }
 }
 
+// get_maxima_positions in arg-max mode from the tile partials of one sub-batch: one wavefront per waveform.
+// Same decision as pick_argmax_kernel (shuffle_picker.hip): with m the row maximum the detections are the positions
+// equal to m if m > 0, nothing if m == 0, and for m < 0 only a constant row (or a one-sample window) has any (Q5).
+__global__ __launch_bounds__(256) void onsets_finalize_kernel(const OnsetPartial* __restrict__ ws, int nslots, int nb, int r,
+                                                              int half, int* __restrict__ counts, int* __restrict__ idx,
+                                                              long long idx_cap) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nb) return;
+    const OnsetPartial* e = ws + (size_t)row * nslots;
+    float m = -INFINITY, lo = INFINITY;
+    for (int s = lane; s < nslots; s += 64)
+        if (e[s].written) { m = fmaxf(m, e[s].m); lo = fminf(lo, e[s].lo); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); lo = fminf(lo, __shfl_xor(lo, o)); }
+    const bool emit = (m > 0.f) || (m < 0.f && (lo == m || half == 0));
+    int nout = 0;
+    if (emit) {
+        const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        int* out = idx + (long long)row * idx_cap;
+        for (int s = 0; s < nslots; ++s) {                       // slots are in time order
+            const OnsetPartial p = e[s];                          // wave-uniform
+            if (!p.written || p.m != m) continue;
+            for (int q0 = 0; q0 < 16 * r; q0 += 64) {
+                const int q = q0 + lane, j = q / r, c = q - j * r;
+                const bool hit = q < 16 * r && ((p.eq[c & 3] >> (j + 16 * (c >> 2))) & 1ull);
+                const unsigned long long hm = __ballot(hit);
+                if (hit) {
+                    const long long pos = nout + __builtin_popcountll(hm & lt_mask);
+                    if (pos < idx_cap) out[pos] = (p.tw_base + j) * r + c;
+                }
+                nout += __builtin_popcountll(hm);
+            }
+        }
+    }
+    if (lane == 0) counts[row] = nout;
+}
+
 constexpr int BODY_S = 192, BODY_RING = 256, BODY_RAWRING = 256;
+constexpr int ONSET_MAX_SEGS = 32;       // seg_policy cuts a waveform into at most 2^5 segments
+
+// slots per waveform of the fused picker's partials for rows of L samples cut into nseg segments
+constexpr int64_t onset_seg_slots(int64_t seg_len) { return seg_len / 16 + 2; }
+constexpr int64_t onset_max_slots(int64_t L) { return L / 16 + 3 * ONSET_MAX_SEGS; }
+
+struct OnsetArgs {                        // non-null ws: stof_forward_onsets
+    OnsetPartial* ws;                     // [<= SUB_BATCH][onset_max_slots(L)]
+    int32_t* counts;
+    int32_t* idx;
+    int64_t idx_cap;
+    int half;
+};
 constexpr int64_t SUB_BATCH = 4096;      // rows whose SGB maps share one workspace
 
 constexpr size_t sgb_lds_bytes() {
@@ -944,7 +1046,7 @@ constexpr size_t sgb_lds_bytes() {
 template <int PREC>
 int launch_forward(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y, int64_t N,
                    int64_t L, void* workspace, hipStream_t stream, void* const* events, int32_t* status,
-                   const int32_t* run_if) {
+                   const int32_t* run_if, const OnsetArgs* onsets = nullptr) {
     const int force_nseg_log2 = desc->seg_policy > 0 ? desc->seg_policy - 1 : -1;
     const int r = desc->upsample_factor;
     const bool has_sgb = desc->semi_global_scale != 1;
@@ -977,7 +1079,7 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
     for (int64_t b0 = 0; b0 < N; b0 += SUB_BATCH) {
         const int64_t nb = (N - b0) < SUB_BATCH ? (N - b0) : SUB_BATCH;
         const float* xb = x + b0 * L;
-        float* yb = y + b0 * L * r;
+        float* yb = y ? y + b0 * L * r : nullptr;
         float* pooled = nullptr;
         float* sgb = nullptr;
         const bool ev = events && b0 == 0;
@@ -1034,6 +1136,14 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         bp.halo = nseg > 1 ? 38 : 0;
         const int64_t nv = nb * nseg;                     // virtual waveforms
         bp.N = (int)nv;
+        bp.onset_ws = nullptr; bp.onset_slots = 0; bp.onset_seg_slots = 0;
+        if (onsets != nullptr) {
+            bp.onset_seg_slots = (int)onset_seg_slots(bp.seg_len);
+            bp.onset_slots = (int)(nseg * bp.onset_seg_slots);
+            bp.onset_ws = onsets->ws;
+            if (hipMemsetAsync(onsets->ws, 0, (size_t)nb * bp.onset_slots * sizeof(OnsetPartial), stream) != hipSuccess)
+                return STOF_ERR_HIP;
+        }
 #ifdef STOF_STAMPS
         if (workspace) bp.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + (size_t)(nb * P * (NF_SGB + NF)) * sizeof(float) + 256);
 #endif
@@ -1044,6 +1154,10 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         hipLaunchKernelGGL((body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>), dim3((unsigned)wgs), dim3(256),
                            Lds::BYTES, stream, bp);
         if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[3]), stream);
+        if (onsets != nullptr)
+            hipLaunchKernelGGL(onsets_finalize_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, stream, onsets->ws,
+                               bp.onset_slots, (int)nb, r, onsets->half, onsets->counts + b0, onsets->idx + b0 * onsets->idx_cap,
+                               (long long)onsets->idx_cap);
     }
     if (hipGetLastError() != hipSuccess) return STOF_ERR_HIP;
     return STOF_OK;
@@ -1051,7 +1165,7 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
 
 int forward_impl(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y, int64_t N, int64_t L,
                  void* workspace, size_t workspace_bytes, void* stream_, void* const* events, int32_t* status,
-                 const int32_t* run_if = nullptr) {
+                 const int32_t* run_if = nullptr, const OnsetArgs* onsets = nullptr) {
     if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     if (desc->precision != STOF_PREC_FP32 && desc->precision != STOF_PREC_F16X3) return STOF_ERR_UNSUPPORTED;
     if (desc->seg_policy < 0 || desc->seg_policy > 6) return STOF_ERR_UNSUPPORTED;
@@ -1063,14 +1177,14 @@ int forward_impl(const stof_net_desc* desc, const void* packed_dev, const float*
     if (has_sgb && L > 0 && P == 0) return STOF_ERR_POOL_EMPTY;        // the pooling fails before the add can (L = 79)
     if (has_sgb && ((L - P * SGB_SCALE) & 1)) return STOF_ERR_ODD_SGB_REMAINDER;
     if (N == 0 || L == 0) return STOF_OK;                 // empty batch: nothing to do
-    if (!packed_dev || !x || !y) return STOF_ERR_BAD_ARG;
+    if (!packed_dev || !x || (!y && !onsets)) return STOF_ERR_BAD_ARG;
     if ((L + GAP) * SUB_BATCH > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;   // local stream rows are int32
     if (has_sgb && (!workspace || workspace_bytes < stof_forward_workspace_bytes(desc, N, L)))
         return STOF_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (desc->precision == STOF_PREC_FP32)
-        return launch_forward<STOF_PREC_FP32>(desc, packed_dev, x, y, N, L, workspace, stream, events, status, run_if);
-    return launch_forward<STOF_PREC_F16X3>(desc, packed_dev, x, y, N, L, workspace, stream, events, status, run_if);
+        return launch_forward<STOF_PREC_FP32>(desc, packed_dev, x, y, N, L, workspace, stream, events, status, run_if, onsets);
+    return launch_forward<STOF_PREC_F16X3>(desc, packed_dev, x, y, N, L, workspace, stream, events, status, run_if, onsets);
 }
 
 }  // namespace
@@ -1105,6 +1219,32 @@ extern "C" int stof_forward_events(const stof_net_desc* desc, const void* packed
     for (int e = 0; e < STOF_FORWARD_EVENTS; ++e)
         if (!events[e]) return STOF_ERR_BAD_ARG;
     return forward_impl(desc, packed_dev, x, y, N, L, workspace, workspace_bytes, stream, events, status_dev);
+}
+
+// The picker fused into the sweep: workspace = the forward's workspace followed by the tile partials of one sub-batch.
+static size_t onsets_partials_offset(const stof_net_desc* desc, int64_t N, int64_t L) {
+    return (stof_forward_workspace_bytes(desc, N, L) + 255) / 256 * 256;
+}
+
+extern "C" size_t stof_forward_onsets_workspace_bytes(const stof_net_desc* desc, int64_t N, int64_t L) {
+    if (!desc || N <= 0 || L <= 0) return 0;
+    const int64_t nb = N < SUB_BATCH ? N : SUB_BATCH;
+    return onsets_partials_offset(desc, N, L) + (size_t)nb * onset_max_slots(L) * sizeof(OnsetPartial);
+}
+
+extern "C" int stof_forward_onsets(const stof_net_desc* desc, const void* packed_dev, const float* x, float* y, int64_t N,
+                                   int64_t L, int32_t window_size, int32_t* counts, int32_t* idx, int64_t idx_cap,
+                                   void* workspace, size_t workspace_bytes, void* stream, int32_t* status_dev) {
+    if (!desc || !counts || (!idx && idx_cap > 0) || idx_cap < 0 || window_size < 0) return STOF_ERR_BAD_ARG;
+    // the fused picker lives in the 16-channel conv_last tile of the split-fp16 sweep
+    if (desc->precision != STOF_PREC_F16X3 || desc->upsample_factor > 16 || L < 32 || getenv("STOF_NO_LAST16") != nullptr)
+        return STOF_ERR_UNSUPPORTED;
+    if (N > 0 && L > 0 && (!workspace || workspace_bytes < stof_forward_onsets_workspace_bytes(desc, N, L))) return STOF_ERR_WORKSPACE;
+    OnsetArgs oa;
+    oa.ws = reinterpret_cast<OnsetPartial*>(static_cast<char*>(workspace) + onsets_partials_offset(desc, N, L));
+    oa.counts = counts; oa.idx = idx; oa.idx_cap = idx_cap;
+    oa.half = (window_size / 2 * 2 + 1 - 1) / 2;                 // utils/mask2samples.py:7-8
+    return forward_impl(desc, packed_dev, x, y, N, L, workspace, workspace_bytes, stream, nullptr, status_dev, nullptr, &oa);
 }
 
 extern "C" int stof_forward_auto(const stof_net_desc* desc, const void* packed_f16x3_dev, const void* packed_fp32_dev,

@@ -171,6 +171,67 @@ class StofNet(nn.Module):
         _lib.check(code, 'stof_forward')
         return y
 
+    # ---- forward with the arg-max picker fused into the sweep ---------------------------------
+    def forward_onsets(self, x, window_size=20, return_map=False, cap=32):
+        """`model(x)` followed by `get_maxima_positions(., window_size, threshold=None)` (main.py:314 -> 320 with th=Null)
+        in one pass: returns (counts[N] int32, idx[N, Kmax] int32) -- the integer onset sample indices of every row, ties
+        and all, identical to `onset_indices(model(x), window_size)` -- and the map too if `return_map`.  Without the map
+        the network output never touches HBM (4 bytes per onset instead of 4*L*r per waveform).  The picker lives in the
+        split-fp16 sweep's 16-channel conv_last tile: for precision='fp32' or upsample_factor > 16 (and for an input
+        that overflows the fp16 range in 'auto' mode) this falls back to forward() + the picker kernel."""
+        from .mask2samples import onset_indices
+        _lib.require_device(x, 'x')
+        if x.dim() != 3 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f'expected input [N, {self.in_channels}, L], got {list(x.shape)}')
+        n, _, L = x.shape
+        r = int(self.upsample_factor)
+        lib = _lib.lib()
+
+        def via_map():
+            y = self.forward(x)
+            counts, idx = onset_indices(y, window_size, None)
+            return (counts, idx, y) if return_map else (counts, idx)
+
+        if not self._supported() or self.precision == 'fp32' or r > 16 or L < 32 or n == 0:
+            return via_map()
+        desc = self._desc(_lib.PREC_F16X3)
+        xc = x.detach().contiguous().float()
+        packed = self._packed_weights(x.device, _lib.PREC_F16X3)
+        ws_bytes = lib.stof_forward_onsets_workspace_bytes(ctypes.byref(desc), n, L)
+        if self._workspace is None or self._workspace.numel() < ws_bytes or self._workspace.device != x.device:
+            self._workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+        if self._status is None or self._status.device != x.device:
+            self._status = torch.zeros(1, dtype=torch.int32, device=x.device)
+        y = torch.empty((n, 1, L * r), dtype=torch.float32, device=x.device) if return_map else None
+        while True:
+            counts = torch.empty((n,), dtype=torch.int32, device=x.device)
+            idx = torch.empty((n, cap), dtype=torch.int32, device=x.device)
+            self._status.zero_()
+            with torch.cuda.device(x.device):
+                code = lib.stof_forward_onsets(ctypes.byref(desc), _lib.ptr(packed), _lib.ptr(xc), _lib.ptr(y), n, L,
+                                               int(window_size), _lib.ptr(counts), _lib.ptr(idx), cap,
+                                               _lib.ptr(self._workspace), self._workspace.numel(),
+                                               _lib.stream_ptr(x.device), _lib.ptr(self._status))
+            if code == _lib.STOF_ERR_UNSUPPORTED:
+                return via_map()
+            if code == _lib.STOF_ERR_ODD_SGB_REMAINDER or code == _lib.STOF_ERR_POOL_EMPTY:
+                return via_map()                                  # raises the reference's error
+            _lib.check(code, 'stof_forward_onsets')
+            kmax = int(torch.maximum(counts.max(), self._status[0] * (cap + 1)))   # the reference's host sync (mask2samples.py:93)
+            if int(self._status.item()):                          # an activation left the fp16 range
+                if self.precision == 'f16x3':
+                    raise FloatingPointError("StofNet(precision='f16x3'): an activation exceeded the fp16 range")
+                saved, self.precision = self.precision, 'fp32'
+                try:
+                    return via_map()
+                finally:
+                    self.precision = saved
+            if kmax <= cap:
+                break
+            cap = kmax                                            # a row with more ties than the buffer holds: once more
+        idx = idx[:, :kmax]
+        return (counts, idx, y) if return_map else (counts, idx)
+
     def fell_back_to_fp32(self) -> bool:
         """'auto' mode: synchronise and tell whether the LAST forward took the exact-fp32 re-run."""
         return self.precision == 'auto' and self._status is not None and int(self._status.item()) != 0

@@ -631,3 +631,79 @@ def test_main_entry_point_end_to_end(dev, tmp_path):
     es2, s2 = entry.main(['model=gradpeak', 'th=1e-3', 'rf_scale_factor=10', 'batch_size=2', 'num_waveforms=4',
                           'num_samples=2000', 'seed=5'])
     assert es2.shape[0] == 4 and s2['model'] == 'gradpeak'
+
+
+# ---------------------------------------------------------------- arg-max picker fused into the sweep
+@pytest.mark.parametrize('precision', ['auto', 'f16x3'])
+def test_forward_onsets_matches_forward_plus_picker_on_golden(dev, precision):
+    """stof_forward_onsets == stof_forward + stof_pick_maxima, bit for bit, and equals the reference's indices."""
+    from stofnet_amd.mask2samples import onset_indices
+    g = golden('f1_armadillo_r4_argmax1024')
+    m = make_model(dev, load_weights('different-armadillo'), 4, precision=precision)
+    x = torch.from_numpy(synth.synth_echo(1024, 2000, seed=int(g['seed']))).to(dev)
+    counts, idx, y = m.forward_onsets(x, 20, return_map=True)
+    c2, i2 = onset_indices(m(x), 20, None)
+    assert torch.equal(y, m(x))
+    assert torch.equal(counts, c2) and torch.equal(idx, i2)
+    assert np.array_equal(idx[:, 0].cpu().numpy(), g['indices'][:, 1])
+    c3, i3 = m.forward_onsets(x, 20)                       # picker-only: the map is never written
+    assert torch.equal(c3, counts) and torch.equal(i3, idx)
+
+
+@pytest.mark.parametrize('r,L,n', [(4, 2000, 300), (10, 2000, 64), (16, 1536, 33), (1, 400, 5), (4, 96, 7), (10, 2000, 3), (4, 1536, 4100)])
+def test_forward_onsets_shapes_batches_segments(dev, r, L, n):
+    """Row lengths that are no multiple of the 16-row tiles, waveform boundaries inside tiles, small batches (segment
+    mode), several sub-batches, r that is no multiple of 4: always the same indices as the map + picker kernel."""
+    from stofnet_amd.mask2samples import onset_indices
+    m = make_model(dev, synth.synth_state_dict(r, seed=r + L), r, precision='auto')
+    x = torch.from_numpy(synth.synth_echo(n, L, seed=n)).to(dev)
+    counts, idx = m.forward_onsets(x, 20)
+    c2, i2 = onset_indices(m(x), 20, None)
+    assert torch.equal(counts, c2) and torch.equal(idx, i2)
+    ref = po.maxima_positions(so.stofnet_forward(synth.synth_state_dict(r, seed=r + L), x[:3].cpu().numpy(), r, 80).numpy(), 20, None)
+    got = [(row, int(t)) for row in range(min(3, n)) for t in idx[row, :int(counts[row])].cpu().numpy()]
+    assert got == [tuple(v) for v in ref.tolist()]
+
+
+def test_forward_onsets_ties_and_degenerate_rows(dev):
+    """Q5 through the fused path: weights that make the network output piecewise constant give plateaus (every tied
+    position is a detection), an all-zero map (no detection), and a constant negative map (every position)."""
+    from stofnet_amd.mask2samples import onset_indices
+    r, L = 4, 320
+    sd = synth.synth_state_dict(r, seed=2)
+    for k in sd:
+        if k.startswith('conv_last'):
+            sd[k] = np.zeros_like(sd[k])
+    x = torch.from_numpy(synth.synth_echo(6, L, seed=1)).to(dev)
+    for bias, expect_count in ((np.zeros(r, np.float32), 0), (np.full(r, -0.5, np.float32), L * r),
+                               (np.array([0.25, 0.25, -1, 0.25], np.float32), 3 * L)):
+        sd['conv_last.bias'] = bias
+        m = make_model(dev, sd, r, precision='auto')
+        counts, idx = m.forward_onsets(x, 20)
+        c2, i2 = onset_indices(m(x), 20, None)
+        assert torch.equal(counts, c2) and torch.equal(idx, i2)
+        assert int(counts[0]) == expect_count
+    # a plateau inside one tile: pin conv_last to copy one channel so neighbouring outputs tie exactly
+    sd = synth.synth_state_dict(r, seed=3)
+    sd['conv_last.weight'][1:] = sd['conv_last.weight'][:1]
+    sd['conv_last.bias'][1:] = sd['conv_last.bias'][:1]
+    m = make_model(dev, sd, r, precision='auto')
+    counts, idx = m.forward_onsets(x, 20)
+    c2, i2 = onset_indices(m(x), 20, None)
+    assert torch.equal(counts, c2) and torch.equal(idx, i2) and int(counts.min()) >= r
+
+
+def test_forward_onsets_falls_back_outside_the_fused_tile(dev):
+    from stofnet_amd.mask2samples import onset_indices
+    x = torch.from_numpy(synth.synth_echo(5, 400, seed=4)).to(dev)
+    for r, precision in ((20, 'auto'), (4, 'fp32')):
+        m = make_model(dev, synth.synth_state_dict(r, seed=9), r, precision=precision)
+        counts, idx = m.forward_onsets(x, 20)
+        c2, i2 = onset_indices(m(x), 20, None)
+        assert torch.equal(counts, c2) and torch.equal(idx, i2)
+    m = make_model(dev, synth.synth_state_dict(4, seed=12), 4, precision='auto')
+    big = x * 3.0e6                                          # fp16 range overflow: exact-fp32 map path
+    counts, idx = m.forward_onsets(big, 20)
+    m32 = make_model(dev, synth.synth_state_dict(4, seed=12), 4, precision='fp32')
+    c2, i2 = onset_indices(m32(big), 20, None)
+    assert torch.equal(counts, c2) and torch.equal(idx, i2)
