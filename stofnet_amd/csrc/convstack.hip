@@ -1005,9 +1005,13 @@ __global__ __launch_bounds__(256) void onsets_finalize_kernel(const OnsetPartial
     if (emit) {
         const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         int* out = idx + (long long)row * idx_cap;
-        for (int s = 0; s < nslots; ++s) {                       // slots are in time order
+        for (int s0 = 0; s0 < nslots; s0 += 64) {                // slots are in time order; almost none holds the maximum
+            const int sl = s0 + lane;
+            unsigned long long match = __ballot(sl < nslots && e[sl].written && e[sl].m == m);
+            while (match) {
+            const int s = s0 + __builtin_ctzll(match);
+            match &= match - 1;
             const OnsetPartial p = e[s];                          // wave-uniform
-            if (!p.written || p.m != m) continue;
             for (int q0 = 0; q0 < 16 * r; q0 += 64) {
                 const int q = q0 + lane, j = q / r, c = q - j * r;
                 const bool hit = q < 16 * r && ((p.eq[c & 3] >> (j + 16 * (c >> 2))) & 1ull);
@@ -1017,6 +1021,7 @@ __global__ __launch_bounds__(256) void onsets_finalize_kernel(const OnsetPartial
                     if (pos < idx_cap) out[pos] = (p.tw_base + j) * r + c;
                 }
                 nout += __builtin_popcountll(hm);
+            }
             }
         }
     }
