@@ -30,6 +30,51 @@ from stofnet_amd import config as config_mod                     # noqa: E402
 from stofnet_amd.metrics import toa_rmse                         # noqa: E402
 
 
+class RunLog:
+    """The reference's `logging` switch (main.py:113-130): falsy = no logging at all; otherwise the run is logged under that
+    group name -- to wandb when it is installed (same project, metric names and summary keys as main.py:115-130,349-373,
+    415-421), else to `<run_name>_<group>.jsonl` next to the script with the same keys, so downstream table scripts find
+    the same fields."""
+
+    SUMMARY_KEYS = ('model_name', 'total_parameters', 'total_jaccard', 'total_inference_time', 'total_distance_mean',
+                    'total_distance_std')
+
+    def __init__(self, cfg):
+        self.enabled = bool(cfg.logging) and int(os.environ.get('RANK', '0')) == 0
+        self.wb = None
+        self.path = None
+        self.name = str(cfg.run_name)
+        if not self.enabled:
+            return
+        try:
+            import wandb
+            self.wb = wandb.init(project='StofNet', resume='allow', anonymous='must', config=cfg.to_container(),
+                                 group=str(cfg.logging))
+            self.name = self.wb.name
+        except ImportError:
+            self.path = script_path / f'{cfg.run_name}_{cfg.logging}.jsonl'
+            self.path.write_text('')
+
+    def log(self, record):
+        if not self.enabled:
+            return
+        if self.wb is not None:
+            self.wb.log(record)
+        else:
+            with open(self.path, 'a') as f:
+                f.write(json.dumps({k: (float(v) if hasattr(v, '__float__') else v) for k, v in record.items()}) + '\n')
+
+    def summary(self, values):
+        if not self.enabled:
+            return
+        if self.wb is not None:
+            for k, v in values.items():
+                self.wb.summary[k] = v
+            self.wb.finish()
+        else:
+            self.log({'summary': values})
+
+
 def load_frames(cfg):
     if cfg.input_file:
         arr = np.load(cfg.input_file).astype(np.float32)
@@ -70,8 +115,14 @@ def main(argv=None):
             model.load_state_dict(torch.load(str(paths[0]), map_location=cfg.device, weights_only=True))
 
     frames, gt = load_frames(cfg)
-    history = train(model, frames, gt, cfg) if (not cfg.evaluate and name == 'stofnet') else None
-    es_all, summary = evaluate(model, name, frames, gt, cfg)
+    log = RunLog(cfg)
+    if log.enabled and str(cfg.run_name) == 'local-run':
+        cfg.run_name = log.name                                          # the reference names checkpoints after the wandb run
+    history = train(model, frames, gt, cfg, log) if (not cfg.evaluate and name == 'stofnet') else None
+    es_all, summary = evaluate(model, name, frames, gt, cfg, log)
+    log.summary({'model_name': name, 'total_parameters': int(sum(p.numel() for p in model.parameters())),
+                 'total_jaccard': summary.get('total_jaccard'), 'total_inference_time': summary['inference_time'],
+                 'total_distance_mean': summary.get('total_distance_mean'), 'total_distance_std': summary.get('total_distance_std')})
     if history is not None:
         summary['train_history'] = history
     if int(os.environ.get('RANK', '0')) == 0:
@@ -79,7 +130,7 @@ def main(argv=None):
     return es_all, summary
 
 
-def train(model, frames, gt, cfg):
+def train(model, frames, gt, cfg, log=None):
     """main.py:199-289 + 403-410 + 423-426 on the HIP training kernels (stofnet_amd/training.py)."""
     import torch.distributed as dist
     from stofnet_amd.sharding import agree_any, rank_batches
@@ -113,6 +164,8 @@ def train(model, frames, gt, cfg):
             sl = slice(b * bs, (b + 1) * bs)
             loss, _ = tr.train_step(torch.from_numpy(tr_x[sl]).to(cfg.device), gt_true_of(tr_gt[sl]))
             tot += float(loss)
+            if log is not None and log.enabled:
+                log.log({'train_step': e * len(mine) + (b - rank) // world + 1, 'train_loss': float(loss)})      # main.py:251-255
         model.eval()
         val = 0.0
         with torch.no_grad():
@@ -122,6 +175,8 @@ def train(model, frames, gt, cfg):
         history.append({'epoch': e, 'lr': tr.lr, 'train_loss': tot / max(len(mine), 1), 'val_loss': val})
         if rank == 0:
             print(json.dumps(history[-1]))
+        if log is not None:
+            log.log({'lr': tr.lr, 'epoch': e})                                                              # main.py:282-286
         if val < best - float(cfg.delta):                                # EarlyStopping (utils/early_stop.py)
             best, bad = val, 0
         else:
@@ -137,7 +192,7 @@ def train(model, frames, gt, cfg):
     return history
 
 
-def evaluate(model, name, frames, gt, cfg):
+def evaluate(model, name, frames, gt, cfg, log=None):
     bs = int(cfg.batch_size)
     results, times = [], []
     with torch.no_grad():
@@ -153,7 +208,11 @@ def evaluate(model, name, frames, gt, cfg):
                 es = out
             torch.cuda.synchronize()
             times.append((time.perf_counter() - tic) / bs)
+            if name == 'stofnet' and getattr(model, 'precision', '') == 'f16x3':
+                model.raise_if_overflow()                    # the fast mode alone has no fp32 re-run ('auto' does)
             results.append(es.reshape(bs, -1).cpu().numpy())
+            if log is not None:
+                log.log({'val_step': b0 // bs + 1, 'inference_time': times[-1]})                            # main.py:349-356
     kmax = max(r.shape[1] for r in results)
     es_all = np.concatenate([np.pad(r, ((0, 0), (0, kmax - r.shape[1]))) for r in results], 0)
     summary = {'model': name, 'waveforms': int(es_all.shape[0]), 'inference_time': float(np.mean(times)),
@@ -162,8 +221,16 @@ def evaluate(model, name, frames, gt, cfg):
         # toa_rmse (main.py:347) on the device kernel
         errs = toa_rmse(torch.from_numpy(gt[:es_all.shape[0]]).to(cfg.device), torch.from_numpy(es_all).to(cfg.device),
                         tol=cfg.etol).cpu()
-        summary['total_distance_mean'] = float(np.nanmean(errs[:, 0].numpy()))
-        summary['total_jaccard'] = float(np.nanmean(errs[:, 3].numpy()))
+        dist_all = errs[:, 0].numpy()
+        with np.errstate(all='ignore'):
+            summary['total_distance_mean'] = float(np.nanmean(dist_all)) if np.isfinite(dist_all).any() else float('nan')
+            summary['total_distance_std'] = float(np.std(dist_all[~np.isnan(dist_all)])) if np.isfinite(dist_all).any() else float('nan')
+            summary['total_jaccard'] = float(np.nanmean(errs[:, 3].numpy()))
+        if log is not None:
+            for k, row in enumerate(errs.numpy()):                                                          # main.py:359-373
+                log.log({'val_idx': k, 'val_toa_distance': row[0], 'val_toa_precision': row[1], 'val_toa_recall': row[2],
+                         'val_toa_jaccard': row[3], 'val_toa_true_positive': row[4], 'val_toa_false_positive': row[5],
+                         'val_toa_false_negative': row[6]})
     return es_all, summary
 
 

@@ -707,3 +707,21 @@ def test_forward_onsets_falls_back_outside_the_fused_tile(dev):
     m32 = make_model(dev, synth.synth_state_dict(4, seed=12), 4, precision='fp32')
     c2, i2 = onset_indices(m32(big), 20, None)
     assert torch.equal(counts, c2) and torch.equal(idx, i2)
+
+
+def test_main_logging_switch_without_wandb(dev):
+    """`logging=<group>` (main.py:113-130): with wandb absent the same metric and summary keys go to a JSON-lines file."""
+    import main as entry
+    path = os.path.join(os.path.dirname(entry.__file__), 'lgtest_unit.jsonl')
+    try:
+        entry.main(['model=stofnet', 'th=Null', 'evaluate=True', 'batch_size=4', 'num_waveforms=8', 'num_samples=400',
+                    'seed=5', 'logging=unit', 'run_name=lgtest'])
+        recs = [json.loads(ln) for ln in open(path)]
+        summ = [r['summary'] for r in recs if 'summary' in r][0]
+        assert set(entry.RunLog.SUMMARY_KEYS) <= set(summ) and summ['total_parameters'] == 645764 and summ['model_name'] == 'stofnet'
+        assert any('val_toa_jaccard' in r for r in recs) and any('inference_time' in r for r in recs)
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    entry.main(['model=stofnet', 'th=Null', 'evaluate=True', 'batch_size=4', 'num_waveforms=4', 'num_samples=400'])   # logging: False
+    assert not os.path.exists(path)
