@@ -28,14 +28,29 @@ __global__ __launch_bounds__(256) void sample_shuffle_kernel(const float* __rest
     const int w0 = tw * SHUF_TW;
     const int wn = min(SHUF_TW, W - w0);
     const float* src = in + (n * (long long)r * C + c) * W + w0;      // row k at + k*C*W
-    for (int k = 0; k < r; ++k)
-        if (tid < wn) tile[k * (SHUF_TW + 1) + tid] = src[(long long)k * C * W + tid];
+    const long long rs = (long long)C * W;
+    // reads: four independent row loads in flight per thread before the first LDS store
+    int k = 0;
+    for (; k + 4 <= r; k += 4) {
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (tid < wn) { v0 = src[k * rs + tid]; v1 = src[(k + 1) * rs + tid]; v2 = src[(k + 2) * rs + tid]; v3 = src[(k + 3) * rs + tid]; }
+        tile[k * (SHUF_TW + 1) + tid] = v0;
+        tile[(k + 1) * (SHUF_TW + 1) + tid] = v1;
+        tile[(k + 2) * (SHUF_TW + 1) + tid] = v2;
+        tile[(k + 3) * (SHUF_TW + 1) + tid] = v3;
+    }
+    for (; k < r; ++k)
+        if (tid < wn) tile[k * (SHUF_TW + 1) + tid] = src[k * rs + tid];
     __syncthreads();
     float* dst = out + (nc * W + w0) * (long long)r;
     const int total = wn * r;
+    const float inv_r = 1.0f / (float)r;
     for (int i = tid; i < total; i += 256) {
-        const int w = i / r, k = i - w * r;
-        dst[i] = tile[k * (SHUF_TW + 1) + w];
+        // i / r without an integer division: exact for i < 2^22 (float quotient + one correction)
+        int w = (int)((float)i * inv_r);
+        int kk = i - w * r;
+        if (kk < 0) { kk += r; w -= 1; } else if (kk >= r) { kk -= r; w += 1; }
+        dst[i] = tile[kk * (SHUF_TW + 1) + w];
     }
 }
 
@@ -49,8 +64,7 @@ __global__ __launch_bounds__(256) void sample_shuffle_kernel(const float* __rest
 // equal to m; if m == 0 nothing is non-zero; if m < 0 a suppressed sample (value 0) outranks m
 // unless every sample is its own window maximum, i.e. the row is constant (or the window is a
 // single sample) -- then every position equal to m is a detection (Q5).  So: one streaming pass
-// for max/min with a per-(chunk, wave) maximum kept in LDS, then only the 1-KiB pieces that
-// contain the maximum are re-read (L2-hot) to list the positions in order.
+// (pick_argmax_kernel below).
 //
 // Threshold mode streams the row through LDS in 4096-sample chunks (+halo, float4 staging); only
 // samples that already pass `s >= th && s != 0` (sparse) pay for the window maximum.  Detections are
@@ -58,8 +72,6 @@ __global__ __launch_bounds__(256) void sample_shuffle_kernel(const float* __rest
 // two-pass variant was measured 2-5x slower at moderate candidate density.)
 // ----------------------------------------------------------------------------------
 constexpr int PK_MAXHALF = 64;
-constexpr int PK_PIECE = 256;     // samples per (wave, iteration) piece in arg-max mode (64 lanes x float4)
-constexpr int PK_MAXPIECES = 8192;
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -72,81 +84,115 @@ __device__ __forceinline__ float wave_min(float v) {
     return v;
 }
 
+// One streaming pass: every lane keeps the maximum of the samples it has seen, the position of its first occurrence
+// and how often it occurred (a lane's positions ascend), plus the minimum.  After the block reduction the detections
+// are the `first` positions of the lanes whose maximum equals the row maximum -- sorted, there are one or a handful --
+// unless some lane saw the maximum twice or the row is a negative constant (every position is a detection): those rows
+// are listed by an ordered second scan (L2-hot).
 __global__ __launch_bounds__(256) void pick_argmax_kernel(const float* __restrict__ scores, int M, int half,
                                                           int* __restrict__ counts, int* __restrict__ idx,
                                                           long long idx_cap) {
-    __shared__ float pmax[PK_MAXPIECES];
     __shared__ float red[2][4];
+    __shared__ int redi[2][4];
+    __shared__ int hitpos[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long row = blockIdx.x;
     const float* s = scores + row * (long long)M;
     int* out = idx + row * idx_cap;
-    const int npieces = (M + PK_PIECE - 1) / PK_PIECE;
     const bool aligned = ((reinterpret_cast<size_t>(s) & 15) == 0);
+    const int nq = (M + 3) >> 2;                                     // 4-sample groups, thread tid takes tid, tid + 256, ...
 
-    auto load_piece = [&](int piece, float (&v)[4]) {
-        const int t0 = piece * PK_PIECE + 4 * lane;
+    auto load_q = [&](int q, float (&v)[4]) {
+        const int t0 = 4 * q;
         if (aligned && t0 + 3 < M) {
-            const float4 q = *reinterpret_cast<const float4*>(s + t0);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            const float4 f = *reinterpret_cast<const float4*>(s + t0);
+            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (t0 + e < M) ? s[t0 + e] : -INFINITY;
+            for (int e = 0; e < 4; ++e) v[e] = (t0 + e < M) ? s[t0 + e] : NAN;       // NaN: never greater, equal or smaller
         }
     };
-
-    float mx = -INFINITY, mn = INFINITY;
-    for (int piece = wave; piece < npieces; piece += 4) {
-        float v[4];
-        load_piece(piece, v);
-        float lm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        const int t0 = piece * PK_PIECE + 4 * lane;
+    float lmax = -INFINITY, lmin = INFINITY;
+    int first = 0, cnt = 0;
+    auto take = [&](int q, const float (&v)[4]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (t0 + e < M) mn = fminf(mn, v[e]);
-        mx = fmaxf(mx, lm);
-        if (piece < PK_MAXPIECES) {
-            lm = wave_max(lm);
-            if (lane == 0) pmax[piece] = lm;
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[e];
+            if (x > lmax) { lmax = x; first = 4 * q + e; cnt = 1; }
+            else if (x == lmax) ++cnt;
+            lmin = fminf(lmin, x);                                    // fminf ignores the NaN padding
         }
+    };
+    int q = tid;
+    for (; q + 768 < nq; q += 1024) {                                 // four 16-byte loads in flight per lane
+        float v0[4], v1[4], v2[4], v3[4];
+        load_q(q, v0); load_q(q + 256, v1); load_q(q + 512, v2); load_q(q + 768, v3);
+        take(q, v0); take(q + 256, v1); take(q + 512, v2); take(q + 768, v3);
     }
-    mx = wave_max(mx);
-    mn = wave_min(mn);
-    if (lane == 0) { red[0][wave] = mx; red[1][wave] = mn; }
+    for (; q < nq; q += 256) {
+        float v0[4];
+        load_q(q, v0);
+        take(q, v0);
+    }
+    float m = wave_max(lmax), lo = wave_min(lmin);
+    if (lane == 0) { red[0][wave] = m; red[1][wave] = lo; }
     __syncthreads();
-    const float m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-    const float lo = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+    m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    lo = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
     // which rows have detections at all (see the header comment)
     const bool emit = (m > 0.f) || (m < 0.f && (lo == m || half == 0));
+    const bool hit = emit && cnt > 0 && lmax == m;
+    const unsigned long long hm = __ballot(hit);
+    int nh = __builtin_popcountll(hm), nc = hit ? cnt : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nc += __shfl_xor(nc, o);
+    if (lane == 0) { redi[0][wave] = nh; redi[1][wave] = nc; }
+    __syncthreads();
+    const int hits = redi[0][0] + redi[0][1] + redi[0][2] + redi[0][3];          // lanes holding the maximum
+    const int total = redi[1][0] + redi[1][1] + redi[1][2] + redi[1][3];         // positions holding the maximum
+    if (!emit || total == 0) {
+        if (tid == 0) counts[row] = 0;
+        return;
+    }
+    if (total == hits) {                                              // every such lane saw it once: `first` is the list
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += redi[0][w];
+        const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (hit) hitpos[woff + __builtin_popcountll(hm & lt_mask)] = first;
+        __syncthreads();
+        if (tid < hits) {                                             // rank sort of <= 256 distinct positions
+            const int mine = hitpos[tid];
+            int rank = 0;
+            for (int k = 0; k < hits; ++k) rank += hitpos[k] < mine;
+            if (rank < idx_cap) out[rank] = mine;
+        }
+        if (tid == 0) counts[row] = hits;
+        return;
+    }
+    // a tie inside one lane's stream or a constant negative row: ordered scan by the first wave
     if (wave != 0) return;
     int nout = 0;
-    if (emit) {
-        const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        for (int piece = 0; piece < npieces; ++piece) {
-            if (piece < PK_MAXPIECES && pmax[piece] != m) continue;      // wave-uniform (LDS broadcast)
-            float v[4];
-            load_piece(piece, v);
-            const int t0 = piece * PK_PIECE + 4 * lane;
-            int nh = 0;
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+        const int qq = q0 + lane;
+        float v[4] = {NAN, NAN, NAN, NAN};
+        if (qq < nq) load_q(qq, v);
+        int nhq = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) nh += (t0 + e < M) && (v[e] == m);
-            // exclusive prefix over lanes (lane order = time order)
-            int incl = nh;
+        for (int e = 0; e < 4; ++e) nhq += (v[e] == m);
+        int incl = nhq;                                               // exclusive prefix over lanes (lane order = time order)
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int y = __shfl_up(incl, o);
-                if (lane >= o) incl += y;
-            }
-            int pos = nout + incl - nh;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if ((t0 + e < M) && (v[e] == m)) {
-                    if (pos < idx_cap) out[pos] = t0 + e;
-                    ++pos;
-                }
-            nout += __shfl(incl, 63);
-            (void)lt_mask;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
         }
+        int pos = nout + incl - nhq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v[e] == m) {
+                if (pos < idx_cap) out[pos] = 4 * qq + e;
+                ++pos;
+            }
+        nout += __shfl(incl, 63);
     }
     if (lane == 0) counts[row] = nout;
 }
