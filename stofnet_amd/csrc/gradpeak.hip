@@ -36,20 +36,23 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void gradpeak_rows_kernel(const fl
                                                                         float* __restrict__ echoes, float* __restrict__ reduced,
                                                                         int* __restrict__ counts, int* __restrict__ flags,
                                                                         double* __restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) float tp[stof_gp::TAPS_LDS];
     __shared__ float rings[ROWS_WAVES][512];
     __shared__ double red[2][ROWS_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stof_gp::stage_taps(tp, taps, cf.radius, tid, blockDim.x);
     if (th_dev != nullptr) {                                   // default threshold computed on the device (Q7)
         cf.th_pos = *th_dev;
         cf.th_neg = -cf.th_pos / 4.0f;                          // models/gradpeak.py:19
     }
+    __syncthreads();
     double mom[2] = {0.0, 0.0};
     for (long long row = (long long)blockIdx.x * ROWS_WAVES + wave; row < N; row += (long long)gridDim.x * ROWS_WAVES) {
         const float* e = env + row * (long long)cf.L;
         float* const out[1] = {MOMENTS ? nullptr : echoes + row * cf.cap * 3};
         RowState st[1];
         stof_gp::stream_rows<1, MOMENTS>(
-            cf, taps, rings[wave], lane, [&](int u, float (&v)[1]) { v[0] = e[u]; }, [&](int, int i) { return e[i]; }, out, st, mom);
+            cf, tp, rings[wave], lane, [&](int u, float (&v)[1]) { v[0] = e[u]; }, [&](int, int i) { return e[i]; }, out, st, mom);
         if constexpr (!MOMENTS) stof_gp::finish_row(st[0], cf, row, out[0], reduced, counts, flags, lane);
     }
     if (MOMENTS) {
@@ -106,12 +109,14 @@ __global__ __launch_bounds__(256, 4) void toa_fused_kernel(const FusedParams p) 
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int n = p.cf.L, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
     const int RG = stof_gp::ring_entries(p.cf.radius);
-    // LDS: pair image [n] | twiddle tables | two gradient rings
+    // LDS: pair image [n] | twiddle tables | tap image | two gradient rings
     cf* const Z = reinterpret_cast<cf*>(lds);
     cf* const ta = Z + n;
     cf* const tb = ta + TW_A;
     const int nb = (n + TW_A - 1) / TW_A;
-    float* const rings = reinterpret_cast<float*>(tb + nb);
+    float* const tp = reinterpret_cast<float*>(tb + nb + (nb & 1));              // 16-byte aligned (tables are 8-byte entries)
+    float* const rings = tp + stof_gp::TAPS_LDS;
+    stof_gp::stage_taps(tp, p.taps, p.cf.radius, tid, T);
     for (int t = tid; t < TW_A + nb; t += T) {
         const double k = t < TW_A ? (double)t : (double)(t - TW_A) * (double)TW_A;
         double sn, cs;
@@ -151,13 +156,16 @@ __global__ __launch_bounds__(256, 4) void toa_fused_kernel(const FusedParams p) 
             });
         __syncthreads();
         const float* const E = reinterpret_cast<const float*>(Z);            // E[2 u + r] = envelope of row r at sample u
+#ifdef STOF_GP_SKIP                                              // diagnostic build: transform + envelope only
+        continue;
+#endif
         for (int r = wave; r < (second ? 2 : 1); r += nwaves) {
             if (r >= 2) break;
             float* const out[1] = {p.echoes + (row + r) * p.cf.cap * 3};
             RowState st[1];
             double mom[2] = {0.0, 0.0};
             stof_gp::stream_rows<1, false>(
-                p.cf, p.taps, rings + (size_t)(wave & 1) * 2 * RG, lane, [&](int u, float (&v)[1]) { v[0] = E[2 * u + r]; },
+                p.cf, tp, rings + (size_t)(wave & 1) * 2 * RG, lane, [&](int u, float (&v)[1]) { v[0] = E[2 * u + r]; },
                 [&](int, int i) { return E[2 * i + r]; }, out, st, mom);
             stof_gp::finish_row(st[0], p.cf, row + r, out[0], p.reduced, p.counts, p.flags, lane);
         }
@@ -168,7 +176,8 @@ constexpr int FUSED_MAX_L = 4096;      // beyond this the envelope kernel + row-
 
 size_t fused_lds_bytes(int64_t n, int radius, stof_fft::Plan* plan) {
     if (n > FUSED_MAX_L || !stof::hilbert_fast_lds_bytes(n, plan)) return 0;
-    return ((size_t)n + stof_fft::twiddle_entries((int)n)) * sizeof(float2) + (size_t)2 * stof_gp::ring_floats(radius) * sizeof(float);
+    return ((size_t)n + stof_fft::twiddle_entries((int)n) + 1) * sizeof(float2) +
+           ((size_t)stof_gp::TAPS_LDS + 2 * stof_gp::ring_floats(radius)) * sizeof(float);
 }
 
 bool bad_common(int64_t N, int64_t L, int32_t grad_step, int32_t radius, int64_t cap) {

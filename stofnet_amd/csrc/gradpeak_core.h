@@ -19,6 +19,13 @@
 namespace stof_gp {
 
 constexpr int MAXRAD = 96;                      // Gaussian radius limit (sigma = (2 g - 1) / 6, rf_scale_factor <= 115)
+constexpr int TAPS_LDS = 2 * MAXRAD + 8;        // floats of the zero-padded tap image in LDS (a multiple of 8)
+
+// copy the taps into their LDS image (all threads of the work-group; the caller synchronises)
+__device__ __forceinline__ void stage_taps(float* __restrict__ tp, const float* __restrict__ taps, int radius, int tid, int T) {
+    const int ntaps = 2 * radius + 1;
+    for (int i = tid; i < TAPS_LDS; i += T) tp[i] = i < ntaps ? taps[i] : 0.f;
+}
 
 struct Config {
     int L;                   // samples per row
@@ -89,8 +96,7 @@ __device__ __forceinline__ void pair_word(RowState& st, int base, unsigned long 
 //   env_pair(u, e)   : e[r] = envelope of row r at sample u, 0 <= u < L
 //   env_at(r, i)     : envelope of row r at sample i (amplitude of a kept peak)
 //   ring             : LDS, NR * ring_floats(radius) floats owned by this wave
-//   taps             : 2 rad + 1 floats in global memory (wave-uniform index: the compiler fetches them with scalar
-//                      loads and feeds them to the fmacs as SGPR operands)
+//   taps             : LDS, 16-byte aligned, the 2 rad + 1 taps followed by zeros up to a multiple of 8 (TAPS_LDS floats)
 //   MOMENTS          : accumulate sum / sum of squares of the blurred gradient instead of pairing (Q7 pre-pass)
 template <int NR, bool MOMENTS, class EnvPair, class EnvAt>
 __device__ __forceinline__ void stream_rows(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring,
@@ -108,14 +114,12 @@ __device__ __forceinline__ void stream_rows(const Config& cf, const float* __res
     // the two envelope samples behind a gradient are fetched one iteration ahead, so that rows streamed from HBM pay
     // the memory latency once and not once per 64 samples
     float ea[NR], eb[NR];
-    auto fetch = [&](int u) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) ea[r] = eb[r] = 0.f;
-        if (u < L && L > 1) {
-            if (u == 0) { env_pair(1, ea); env_pair(0, eb); }
-            else if (u == L - 1) { env_pair(L - 1, ea); env_pair(L - 2, eb); }
-            else { env_pair(u + 1, ea); env_pair(u - 1, eb); }
-        }
+    auto fetch = [&](int u) {                                 // branch-free: clamped indices, the caller masks u >= L
+        const int uc = u < L ? u : L - 1;
+        const int ia = (uc >= L - 1) ? L - 1 : uc + 1;        // u = 0: 1;  u = L-1: L-1;  else u+1
+        const int ib = (uc == 0) ? 0 : ((uc >= L - 1) ? L - 2 : uc - 1);
+        env_pair(ia, ea);
+        env_pair(ib > 0 ? ib : 0, eb);
     };
     fetch(lane);
     for (int c = 0; c <= cend; ++c) {
@@ -136,24 +140,28 @@ __device__ __forceinline__ void stream_rows(const Config& cf, const float* __res
         float sm[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) sm[r] = 0.f;
-        // 2 rad + 1 taps, four at a time so that the ring reads of a group are in flight together; the fmaf chain keeps
-        // the tap order, i.e. the reference's rounding
+        // 2 rad + 1 taps, eight at a time: the taps come from LDS as two 16-byte broadcast reads (zero padded to a
+        // multiple of 8 by the caller) and the ring reads of a group are in flight together; the fmaf chain keeps the
+        // tap order, i.e. the reference's rounding (the padding adds zeros at the end of the chain).  Reading the taps
+        // from global memory made every group wait for a vector load (vmcnt(0)): ~3x the time of this stage.
         const int ntaps = 2 * rad + 1, s0 = (u - 2 * rad) & rmask;
-        int j = 0;
-        for (; j + 4 <= ntaps; j += 4) {
-            const float t0 = taps[j], t1 = taps[j + 1], t2 = taps[j + 2], t3 = taps[j + 3];
+        auto tap_group = [&](int j) {
+            const float4 ta = *reinterpret_cast<const float4*>(taps + j), tb = *reinterpret_cast<const float4*>(taps + j + 4);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const float* rr = ring + r * 2 * RG + s0 + j;
-                const float g0 = rr[0], g1 = rr[1], g2 = rr[2], g3 = rr[3];
-                sm[r] = fmaf(t3, g3, fmaf(t2, g2, fmaf(t1, g1, fmaf(t0, g0, sm[r]))));
+                const float g0 = rr[0], g1 = rr[1], g2 = rr[2], g3 = rr[3], g4 = rr[4], g5 = rr[5], g6 = rr[6], g7 = rr[7];
+                float a = sm[r];
+                a = fmaf(ta.x, g0, a); a = fmaf(ta.y, g1, a); a = fmaf(ta.z, g2, a); a = fmaf(ta.w, g3, a);
+                a = fmaf(tb.x, g4, a); a = fmaf(tb.y, g5, a); a = fmaf(tb.z, g6, a); a = fmaf(tb.w, g7, a);
+                sm[r] = a;
             }
-        }
-        for (; j < ntaps; ++j) {
-            const float t = taps[j];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) sm[r] = fmaf(t, ring[r * 2 * RG + s0 + j], sm[r]);
-        }
+        };
+        // straight-line code for the two radii the reference uses (rf 10: 11 taps, rf 20: 31 taps): no loop control on
+        // the scalar unit, which 16 waves of a CU share
+        if (ntaps <= 16) { tap_group(0); tap_group(8); }
+        else if (ntaps <= 32) { tap_group(0); tap_group(8); tap_group(16); tap_group(24); }
+        else for (int j = 0; j < ntaps; j += 8) tap_group(j);
         if (MOMENTS) {
             if (in_row) {
 #pragma unroll
