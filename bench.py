@@ -60,6 +60,9 @@ def parse_args(argv=None):
     ap.add_argument('--rows', type=int, default=0, help='override the rows per GPU of the chosen config (smoke runs)')
     ap.add_argument('--dry-run', action='store_true',
                     help='rehearse the launcher and the distributed plumbing on the CPU (gloo, no kernels): tests only')
+    ap.add_argument('--rehearse-on-one-gpu', action='store_true',
+                    help='rehearsal of the N-rank path on a one-GPU box: every rank uses cuda:0 and the collectives go over '
+                         'gloo (RCCL needs one GPU per rank); the kernels and all rank-dependent code are the real ones')
     args = ap.parse_args(argv)
     if args.mode == 'train':
         args.config = 'C5'
@@ -193,6 +196,8 @@ class Dist:
             raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: launch with '
                              f'`python bench.py --gpus N` or torch.distributed.run --nproc-per-node N')
         self.dist = None
+        if getattr(args, 'rehearse_on_one_gpu', False) and backend == 'nccl':
+            backend, self.local_rank = 'gloo-gpu', 0
         self.dev = torch.device('cpu') if backend == 'gloo' else torch.device('cuda', self.local_rank)
         if self.world > 1:
             import torch.distributed as dist
@@ -205,7 +210,7 @@ class Dist:
             else:
                 dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
             self.dist = dist
-        if backend == 'nccl':
+        if backend != 'gloo':
             torch.cuda.set_device(self.dev)
 
     def barrier(self):
