@@ -47,7 +47,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if not os.path.exists(path):
             raise RuntimeError(f'listed source {path} is missing: refusing to link a library without its symbols')
         obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
-        cmd = [hipcc, '-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-x', 'hip', '-c', path, '-o', obj]
+        cmd = [hipcc, '-O3', '-std=c++17', '-fPIC', '-fconstexpr-steps=100000000', f'--offload-arch={ARCH}', '-x', 'hip', '-c', path, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -342,6 +342,115 @@ __global__ __launch_bounds__(512) void hilbert_pairs_kernel(const float* __restr
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Compile-time plans for the row lengths the reference's datasets produce (fft_small.h: analytic_ct).  A work-group
+// holds PPW pairs (one slot of N complex values each, WPP waves per slot) and ONE full twiddle table w_N^t copied from
+// a compile-time constant array; with WPP = 1 a wave owns its slot and no barrier separates the passes (LDS accesses
+// of one wave execute in order).
+// ----------------------------------------------------------------------------------------------------------------
+template <int N> struct CtTwiddles {
+    static constexpr int K = stof_fft::ct_plan_for(N).table;
+    static __device__ const stof_fft::TwTable<K> table;
+};
+template <int N> __device__ constexpr stof_fft::TwTable<CtTwiddles<N>::K> CtTwiddles<N>::table = stof_fft::make_tw_table<N, CtTwiddles<N>::K>();
+
+template <int N, int WPP, int PPW>
+__global__ __launch_bounds__(64 * WPP * PPW) void hilbert_ct_kernel(const float* __restrict__ x, long long nrows,
+                                                                     float* __restrict__ env, float* __restrict__ re,
+                                                                     float* __restrict__ im, int diag) {
+    using namespace stof_fft;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    constexpr int T = 64 * WPP, TT = T * PPW, IO = (N / 4 + T - 1) / T;
+    constexpr int TW = CtTwiddles<N>::K, TWP = (TW + 1) / 2 * 2, SLOT = ct_slot_entries(N);
+    cf* const W = reinterpret_cast<cf*>(lds);
+    const int slot = threadIdx.x / T, tid = threadIdx.x % T;
+    cf* const Z = W + TWP + slot * SLOT;
+    const long long npairs = (nrows + 1) / 2, stride = (long long)gridDim.x * PPW;
+    long long pr = (long long)blockIdx.x * PPW + slot;
+
+    if (diag & 8) return;
+    // rows of the first pair on their way while the twiddle table is copied
+    stof_io::PairRegs<IO> cur;
+    auto fetch = [&](stof_io::PairRegs<IO>& r, long long p) {
+        if (p < npairs) {
+            const float* xr = x + 2 * p * (size_t)N;
+            stof_io::load_pair_regs(r, xr, 2 * p + 1 < nrows ? xr + N : nullptr, N, tid, T);
+        }
+    };
+    if (!(diag & 4)) fetch(cur, pr);
+    {
+        const float2* src = reinterpret_cast<const float2*>(CtTwiddles<N>::table.w);
+        for (int i = threadIdx.x; i < TW; i += TT) lds[i] = src[i];
+    }
+    __syncthreads();
+    if (diag & 4) return;
+    for (long long p0 = (long long)blockIdx.x * PPW; p0 < npairs; p0 += stride, pr += stride) {
+        const bool active = pr < npairs;
+        if (WPP == 1 && !active) break;                          // a lone wave: nobody waits for it
+        if (WPP > 1) __syncthreads();                             // previous pair fully read back
+        if (active) stof_io::stage_pair<IO, true>(Z, cur, N, tid, T);
+        if (WPP > 1) __syncthreads();
+        if (!(diag & 1)) analytic_ct<N, T>(Z, W, tid, [] { if (WPP > 1) __syncthreads(); });   // idle slots keep the barrier count
+        if (!active) continue;
+        if (diag & 2) { if (Z[tid].x == 123.456f) env[tid] = 1.f; fetch(cur, pr + stride); continue; }
+        const long long row = 2 * pr;
+        const bool second = row + 1 < nrows;
+        float* const e1 = env ? env + row * (size_t)N : nullptr;
+        float* const r1 = re ? re + row * (size_t)N : nullptr;
+        float* const i1 = im ? im + row * (size_t)N : nullptr;
+        stof_io::unmix_pair_regs<IO, true>(
+            Z, cur, N, tid, T,
+            [&](int q, const float (&xa)[4], const float (&v1)[4], const float (&xb)[4], const float (&v2)[4]) {
+                using stof_io::envelope;
+                if (e1) {
+                    *reinterpret_cast<float4*>(e1 + 4 * q) = make_float4(envelope(xa[0], v1[0]), envelope(xa[1], v1[1]),
+                                                                         envelope(xa[2], v1[2]), envelope(xa[3], v1[3]));
+                    if (second)
+                        *reinterpret_cast<float4*>(e1 + N + 4 * q) = make_float4(envelope(xb[0], v2[0]), envelope(xb[1], v2[1]),
+                                                                                 envelope(xb[2], v2[2]), envelope(xb[3], v2[3]));
+                }
+                if (r1) {
+                    *reinterpret_cast<float4*>(r1 + 4 * q) = make_float4(xa[0], xa[1], xa[2], xa[3]);
+                    if (second) *reinterpret_cast<float4*>(r1 + N + 4 * q) = make_float4(xb[0], xb[1], xb[2], xb[3]);
+                }
+                if (i1) {
+                    *reinterpret_cast<float4*>(i1 + 4 * q) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+                    if (second) *reinterpret_cast<float4*>(i1 + N + 4 * q) = make_float4(v2[0], v2[1], v2[2], v2[3]);
+                }
+            });
+        fetch(cur, pr + stride);                                   // next pair's rows (its latency hides behind the stores)
+    }
+}
+
+template <int N, int WPP, int PPW>
+int launch_ct(const float* x, int64_t nrows, float* env, float* re, float* im, int ncu, hipStream_t stream) {
+    constexpr size_t lds = ((size_t)(CtTwiddles<N>::K + 1) / 2 * 2 + (size_t)PPW * stof_fft::ct_slot_entries(N)) * sizeof(float2);
+    static_assert(lds <= (size_t)LDS_BYTES, "slots + table exceed LDS");
+    static stof::LdsLimitOnce once;
+    if (int st = once.ensure(reinterpret_cast<const void*>(&hilbert_ct_kernel<N, WPP, PPW>), LDS_BYTES)) return st;
+    const int64_t npairs = (nrows + 1) / 2, groups = (npairs + PPW - 1) / PPW;
+    int64_t grid = (int64_t)ncu * (int64_t)((size_t)LDS_BYTES / lds);
+    if (grid > groups) grid = groups;
+    hipLaunchKernelGGL((hilbert_ct_kernel<N, WPP, PPW>), dim3((unsigned)grid), dim3(64 * WPP * PPW), lds, stream, x,
+                       (long long)nrows, env, re, im, getenv("STOF_HILBERT_DIAG") ? atoi(getenv("STOF_HILBERT_DIAG")) : 0);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+// lengths with a compile-time plan; returns -1 if n has none (or STOF_HILBERT_CT=0 asks for the run-time plan)
+int try_launch_ct(const float* x, int64_t nrows, int64_t n, float* env, float* re, float* im, int ncu, hipStream_t stream) {
+    static const int mode = [] { const char* e = getenv("STOF_HILBERT_CT"); return e ? atoi(e) : 1; }();
+    if (mode == 0) return -1;
+    for (const void* p : {(const void*)x, (const void*)env, (const void*)re, (const void*)im})
+        if (reinterpret_cast<size_t>(p) & 15) return -1;        // 16-byte row accesses
+    switch (n) {
+        case 1536: return mode == 2 ? launch_ct<1536, 2, 4>(x, nrows, env, re, im, ncu, stream)
+                                    : launch_ct<1536, 1, 4>(x, nrows, env, re, im, ncu, stream);
+        case 2000: return mode == 2 ? launch_ct<2000, 2, 4>(x, nrows, env, re, im, ncu, stream)
+                                    : launch_ct<2000, 1, 4>(x, nrows, env, re, im, ncu, stream);
+        default: return -1;
+    }
+}
+
 }  // namespace
 
 namespace stof {
@@ -380,6 +489,10 @@ extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, fl
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int ncu = stof::device_cu_count();
 
+    {
+        const int st = try_launch_ct(x, N, n, env, re, im, ncu, stream);
+        if (st >= 0) return st;
+    }
     stof_fft::Plan fplan;
     if (const size_t flds = stof::hilbert_fast_lds_bytes(n, &fplan)) {
         static stof::LdsLimitOnce fast_once;

@@ -101,6 +101,68 @@ __device__ __forceinline__ void unmix_pair(const cf* __restrict__ Z, const float
     }
 }
 
-__device__ __forceinline__ float envelope(float re, float im) { return sqrtf(fmaf(re, re, im * im)); }   // |complex64|
+// ---- the same movement with the rows kept in registers ---------------------------------------------------------------
+// A thread's 16-byte pieces q = tid + k T (k < IO) of both rows stay in registers from the load to the un-mixing, so the
+// rows are read from HBM once, and a caller can issue the NEXT pair's loads before it transforms the current one.
+// Requires n % 4 == 0, 16-byte aligned rows and n <= 4 T IO.
+template <int IO>
+struct PairRegs {
+    float4 a[IO], b[IO];
+};
+
+template <int IO>
+__device__ __forceinline__ void load_pair_regs(PairRegs<IO>& r, const float* __restrict__ x1, const float* __restrict__ x2,
+                                               int n, int tid, int T) {
+    const int nq = n >> 2;
+#pragma unroll
+    for (int k = 0; k < IO; ++k) {
+        const int q = tid + k * T;
+        r.a[k] = r.b[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq) {
+            r.a[k] = *reinterpret_cast<const float4*>(x1 + 4 * q);
+            if (x2) r.b[k] = *reinterpret_cast<const float4*>(x2 + 4 * q);
+        }
+    }
+}
+
+// PADDED: Z is the padded slot of fft_small.h's compile-time plans (two complex values after every 16)
+template <int IO, bool PADDED = false>
+__device__ __forceinline__ void stage_pair(cf* __restrict__ Z, const PairRegs<IO>& r, int n, int tid, int T) {
+    const int nq = n >> 2;
+#pragma unroll
+    for (int k = 0; k < IO; ++k) {
+        const int q = tid + k * T;
+        if (q < nq) {
+            float4* d = reinterpret_cast<float4*>(Z + (PADDED ? 4 * q + 2 * (q >> 2) : 4 * q));
+            d[0] = make_float4(r.a[k].x, r.b[k].x, r.a[k].y, r.b[k].y);
+            d[1] = make_float4(r.a[k].z, r.b[k].z, r.a[k].w, r.b[k].w);
+        }
+    }
+}
+
+// emit4(q, x1[4], v1[4], x2[4], v2[4]) as in unmix_pair
+template <int IO, bool PADDED = false, class Emit4>
+__device__ __forceinline__ void unmix_pair_regs(const cf* __restrict__ Z, const PairRegs<IO>& r, int n, int tid, int T,
+                                                Emit4 emit4) {
+    const int nq = n >> 2;
+#pragma unroll
+    for (int k = 0; k < IO; ++k) {
+        const int q = tid + k * T;
+        if (q < nq) {
+            const float4* s = reinterpret_cast<const float4*>(Z + (PADDED ? 4 * q + 2 * (q >> 2) : 4 * q));
+            const float4 z0 = s[0], z1 = s[1];
+            const float xa[4] = {r.a[k].x, r.a[k].y, r.a[k].z, r.a[k].w}, xb[4] = {r.b[k].x, r.b[k].y, r.b[k].z, r.b[k].w};
+            const float re[4] = {z0.x, z0.z, z1.x, z1.z}, im[4] = {z0.y, z0.w, z1.y, z1.w};
+            float v1[4], v2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v1[e] = im[e] - xb[e]; v2[e] = xa[e] - re[e]; }
+            emit4(q, xa, v1, xb, v2);
+        }
+    }
+}
+
+// |complex64| for the envelope: v_sqrt_f32 (1 ulp; the correctly rounded sqrtf costs ~10 instructions per sample, a
+// fifth of these kernels' VALU work) -- the envelope's tolerance is 1e-5 absolute
+__device__ __forceinline__ float envelope(float re, float im) { return __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)); }
 
 }  // namespace stof_io

@@ -52,9 +52,69 @@ extern "C" int fft_butterfly(int R, float* z) {
         case 3: Bf<3>::run(*reinterpret_cast<cf(*)[3]>(x)); return 1;
         case 4: Bf<4>::run(*reinterpret_cast<cf(*)[4]>(x)); return 1;
         case 5: Bf<5>::run(*reinterpret_cast<cf(*)[5]>(x)); return 1;
+        case 6: Bf<6>::run(*reinterpret_cast<cf(*)[6]>(x)); return 1;
         case 8: Bf<8>::run(*reinterpret_cast<cf(*)[8]>(x)); return 1;
+        case 10: Bf<10>::run(*reinterpret_cast<cf(*)[10]>(x)); return 1;
         case 16: Bf<16>::run(*reinterpret_cast<cf(*)[16]>(x)); return 1;
         case 25: Bf<25>::run(*reinterpret_cast<cf(*)[25]>(x)); return 1;
     }
+    return 0;
+}
+
+// ---- compile-time plans: the passes of analytic_ct<N, T> with the T "threads" run one after the other per pass ------
+template <int N, int T, int S, int M>
+static void host_level(cf* Z, const cf* W) {
+    constexpr CtPlan P = ct_plan_for(N);
+    if constexpr (S < P.npass) {
+        constexpr int R = P.radix[S];
+        for (int tid = 0; tid < T; ++tid) ct_pass<N, M, R, false, T>(Z, W, tid);
+        host_level<N, T, S + 1, M / R>(Z, W);
+        for (int tid = 0; tid < T; ++tid) ct_pass<N, M, R, true, T>(Z, W, tid);
+    } else {
+        for (int tid = 0; tid < T; ++tid) ct_middle16<N, T>(Z, tid);
+    }
+}
+
+template <int N>
+static int run_ct(float* z, int nthreads) {
+    constexpr CtPlan P = ct_plan_for(N);
+    static constexpr TwTable<P.table> table = make_tw_table<N, P.table>();
+    const cf* W = reinterpret_cast<const cf*>(table.w);
+    std::vector<cf> slot(ct_slot_entries(N));                       // padded layout: 2 values after every 16
+    cf* in = reinterpret_cast<cf*>(z);
+    for (int i = 0; i < N; ++i) slot[ct_padded(i)] = in[i];
+    cf* Z = slot.data();
+    if (nthreads == 64) host_level<N, 64, 0, N>(Z, W);
+    else if (nthreads == 128) host_level<N, 128, 0, N>(Z, W);
+    else if (nthreads == 256) host_level<N, 256, 0, N>(Z, W);
+    else return 0;
+    for (int i = 0; i < N; ++i) in[i] = slot[ct_padded(i)];
+    return 1;
+}
+
+extern "C" int fft_analytic_ct(int n, float* z, int nthreads) {
+    switch (n) {
+        case 96: return run_ct<96>(z, nthreads);
+        case 1536: return run_ct<1536>(z, nthreads);
+        case 2000: return run_ct<2000>(z, nthreads);
+        case 2048: return run_ct<2048>(z, nthreads);
+        case 4000: return run_ct<4000>(z, nthreads);
+        case 4096: return run_ct<4096>(z, nthreads);
+    }
+    return 0;
+}
+
+extern "C" int fft_ct_plan(int n, int* radix_out, int* table_out) {
+    const CtPlan p = ct_plan_for(n);
+    if (p.npass < 0) return -1;
+    for (int i = 0; i < p.npass; ++i) radix_out[i] = p.radix[i];
+    *table_out = p.table;
+    return p.npass;
+}
+
+// w_n^k of the compile-time table (checked against numpy)
+extern "C" int fft_ct_table(int n, float* out) {
+    if (n == 2000) { static constexpr TwTable<400> t = make_tw_table<2000, 400>(); for (int k = 0; k < 400; ++k) { out[2 * k] = t.w[k].x; out[2 * k + 1] = t.w[k].y; } return 400; }
+    if (n == 1536) { static constexpr TwTable<256> t = make_tw_table<1536, 256>(); for (int k = 0; k < 256; ++k) { out[2 * k] = t.w[k].x; out[2 * k + 1] = t.w[k].y; } return 256; }
     return 0;
 }

@@ -8,11 +8,14 @@ from stofnet_amd.gradpeak import toa_detect
 
 dev = torch.device('cuda:0')
 reps = int(os.environ.get('REPS', '5'))
+only = os.environ.get('ONLY')
 for n, rows in ((2000, 4096), (8000, 4096), (20000, 1024)):
+    if only and int(only) != n:
+        continue
     x = torch.from_numpy(synth.synth_randn(rows, n, seed=1)).to(dev)[:, 0].contiguous()
     for _ in range(reps):
         hilbert_envelope(x)
 x = torch.from_numpy(synth.synth_echo(4096, 2000, seed=3, noise=0.01)).to(dev)[:, 0].contiguous()
-for _ in range(reps):
+for _ in range(0 if only else reps):
     toa_detect(x, 1e-3, 10)
 torch.cuda.synchronize()
