@@ -42,13 +42,29 @@
 namespace stof_fft {
 
 #if defined(__HIPCC__)
-typedef float cf __attribute__((ext_vector_type(2)));            // one aligned VGPR pair: (re, im)
+// one aligned VGPR pair: (re, im).  may_alias: the kernels move the same LDS bytes as 16-byte pieces (pair_io.h) and as
+// floats (GradPeak streams envelopes out of the transform's buffer); without it type-based alias analysis lets the
+// compiler move a complex read across such a store (seen: the first pass of n = 1536 read rows before they were staged).
+typedef float cf __attribute__((ext_vector_type(2), may_alias));
 #else
 struct alignas(8) cf {
     float x, y;
 };
 #endif
 STOF_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+
+// Ordering point for LDS that ONE wavefront shares among its lanes.  The hardware executes a wave's LDS instructions
+// in order, so no s_barrier / s_waitcnt is needed, but the compiler reasons per thread: it may move a lane's read of
+// ANOTHER lane's slot above its own earlier store to a different address (seen: the first pass of n = 1536 was
+// scheduled before the last row pieces were staged).  A wavefront-scope release / acquire pair around a wave barrier
+// pins the order and emits no instruction.
+STOF_HD void wave_lds_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 
 #if defined(__HIP_DEVICE_COMPILE__)
 STOF_HD cf cadd(cf a, cf b) { return a + b; }
@@ -371,7 +387,7 @@ STOF_HD void run_pass(int R, cf* Z, int n, int m, const Twiddles& tw, int tid, i
 }
 
 // analytic signal of the n complex values in Z, in place: Z <- ifft(H .* fft(Z)).  `sync()` separates the passes
-// (a work-group barrier, or nothing when one wave owns Z).
+// (a work-group barrier, or wave_lds_sync() when one wave owns Z).
 template <class Sync>
 STOF_HD void analytic_in_place(cf* Z, const Plan& plan, const Twiddles& tw, int tid, int nthreads, Sync sync) {
     const int n = plan.n, last = plan.npass - 1;

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 4) void toa_fused_kernel(const FusedParams p) 
                 float ea[4], eb[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { ea[e] = stof_io::envelope(xa[e], v1[e]); eb[e] = stof_io::envelope(xb[e], v2[e]); }
-                float4* d = reinterpret_cast<float4*>(Z + 4 * q);
+                stof_io::f4a* d = reinterpret_cast<stof_io::f4a*>(Z + 4 * q);
                 d[0] = make_float4(ea[0], eb[0], ea[1], eb[1]);
                 d[1] = make_float4(ea[2], eb[2], ea[3], eb[3]);
                 if (eo) {

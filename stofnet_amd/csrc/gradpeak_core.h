@@ -15,6 +15,7 @@
 // one iteration later (an edge at the last lane needs the first flag of the next word).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "fft_small.h"      // wave_lds_sync
 
 namespace stof_gp {
 
@@ -40,8 +41,8 @@ struct Config {
 // ring entries for a radius: the blur of 64 samples reads 64 + 2 rad gradients.  Every gradient is stored twice, at
 // slot and slot + ring_entries, so the 2 rad + 1 reads of a sample are `base + j` with no wrap arithmetic (one
 // ds_read with an immediate offset per tap); a row's ring therefore takes 2 * ring_entries floats.
-__host__ __device__ inline int ring_entries(int radius) { return radius <= 32 ? 128 : 256; }
-__host__ __device__ inline int ring_floats(int radius) { return 2 * ring_entries(radius); }
+__host__ __device__ constexpr int ring_entries(int radius) { return radius <= 32 ? 128 : 256; }
+__host__ __device__ constexpr int ring_floats(int radius) { return 2 * ring_entries(radius); }
 
 struct RowState {
     int last_ap = -1;          // most recent rising-slope edge seen so far (carry across words)
@@ -110,6 +111,7 @@ __device__ __forceinline__ void stream_rows(const Config& cf, const float* __res
 #pragma unroll
         for (int r = 0; r < NR; ++r) ring[r * 2 * RG + q] = 0.f;
     }
+    stof_fft::wave_lds_sync();
     const int cend = (L - 1 + rad) / 64 + 1;                  // one extra iteration flushes the last word
     // the two envelope samples behind a gradient are fetched one iteration ahead, so that rows streamed from HBM pay
     // the memory latency once and not once per 64 samples
@@ -129,11 +131,16 @@ __device__ __forceinline__ void stream_rows(const Config& cf, const float* __res
 #pragma unroll
         for (int r = 0; r < NR; ++r) g[r] = (u < L && L > 1) ? (ea[r] - eb[r]) / den : 0.f;
         fetch(u + 64);
+        // the ring is shared by the lanes of this wave only: wave_lds_sync() orders a lane's reads of its neighbours'
+        // gradients behind their stores (and the previous word's reads ahead of these stores) for the compiler; the
+        // hardware executes a wave's LDS instructions in order
+        stof_fft::wave_lds_sync();
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             ring[r * 2 * RG + (u & rmask)] = g[r];
             ring[r * 2 * RG + (u & rmask) + RG] = g[r];
         }
+        stof_fft::wave_lds_sync();
         // blurred gradient of sample i = u - rad from the gradients i - rad .. i + rad = u - 2 rad .. u
         const int i = u - rad;
         const bool in_row = (i >= 0) && (i < L);

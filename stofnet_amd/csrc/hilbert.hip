@@ -1,7 +1,8 @@
 // hilbert_transform (utils/hilbert.py:5-21): v = ifft(H .* fft(y)) along the last dim with
 //   H = [1, 2 (bins 1..n/2-1), 1 (bin n/2), 0 ...]            (Q6: for odd n bin n/2 is not doubled)
 //
-// Two kernels:
+// Three kernels:
+//   hilbert_ct_kernel      (row lengths 1536 / 2000 / 2048 / 4000 / 4096: compile-time plan, see below)
 //   hilbert_pairs_kernel   (fast path: n even with prime factors 2, 3, 5 only and 8 n bytes within the LDS budget)
 //       one work-group per PAIR of rows; the pair rides one complex transform z = x1 + i x2 that lives in LDS; few
 //       passes of register butterflies of radix up to 25 with the filter fused into the middle pass (fft_small.h);
@@ -25,6 +26,7 @@
 #include "stof_hip_util.h"
 #include "fft_small.h"
 #include "pair_io.h"
+#include "ct_twiddles.h"
 
 namespace {
 
@@ -344,31 +346,29 @@ __global__ __launch_bounds__(512) void hilbert_pairs_kernel(const float* __restr
 
 // ----------------------------------------------------------------------------------------------------------------
 // Compile-time plans for the row lengths the reference's datasets produce (fft_small.h: analytic_ct).  A work-group
-// holds PPW pairs (one slot of N complex values each, WPP waves per slot) and ONE full twiddle table w_N^t copied from
-// a compile-time constant array; with WPP = 1 a wave owns its slot and no barrier separates the passes (LDS accesses
-// of one wave execute in order).
+// holds PPW pairs (one padded slot each, WPP waves per slot) and ONE twiddle table (the first N / min-radix powers of
+// w_N) copied from a compile-time constant array; with WPP = 1 a wave owns its slot and no barrier separates the
+// passes, only wave_lds_sync() (LDS accesses of one wave execute in order; the compiler must be told).  The pair's rows stay in registers from the load to the
+// un-mixing (read from HBM once); the next pair's rows are requested before the stores of the current one drain.
+// Measured on [4096, 2000] (rocprofv3, kernel only): 24.2 us against 41.8 us for the run-time plan kernel below;
+// phases: launch + table 3.0, rows in 4.4, transform 13.3, un-mixing + envelope + stores 3.5 us.
 // ----------------------------------------------------------------------------------------------------------------
-template <int N> struct CtTwiddles {
-    static constexpr int K = stof_fft::ct_plan_for(N).table;
-    static __device__ const stof_fft::TwTable<K> table;
-};
-template <int N> __device__ constexpr stof_fft::TwTable<CtTwiddles<N>::K> CtTwiddles<N>::table = stof_fft::make_tw_table<N, CtTwiddles<N>::K>();
+using stof_ct::CtTwiddles;
 
 template <int N, int WPP, int PPW>
 __global__ __launch_bounds__(64 * WPP * PPW) void hilbert_ct_kernel(const float* __restrict__ x, long long nrows,
                                                                      float* __restrict__ env, float* __restrict__ re,
-                                                                     float* __restrict__ im, int diag) {
+                                                                     float* __restrict__ im) {
     using namespace stof_fft;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     constexpr int T = 64 * WPP, TT = T * PPW, IO = (N / 4 + T - 1) / T;
-    constexpr int TW = CtTwiddles<N>::K, TWP = (TW + 1) / 2 * 2, SLOT = ct_slot_entries(N);
+    constexpr int TWP = stof_ct::twiddle_lds_entries<N>(), SLOT = ct_slot_entries(N);
     cf* const W = reinterpret_cast<cf*>(lds);
     const int slot = threadIdx.x / T, tid = threadIdx.x % T;
     cf* const Z = W + TWP + slot * SLOT;
     const long long npairs = (nrows + 1) / 2, stride = (long long)gridDim.x * PPW;
     long long pr = (long long)blockIdx.x * PPW + slot;
 
-    if (diag & 8) return;
     // rows of the first pair on their way while the twiddle table is copied
     stof_io::PairRegs<IO> cur;
     auto fetch = [&](stof_io::PairRegs<IO>& r, long long p) {
@@ -377,22 +377,18 @@ __global__ __launch_bounds__(64 * WPP * PPW) void hilbert_ct_kernel(const float*
             stof_io::load_pair_regs(r, xr, 2 * p + 1 < nrows ? xr + N : nullptr, N, tid, T);
         }
     };
-    if (!(diag & 4)) fetch(cur, pr);
-    {
-        const float2* src = reinterpret_cast<const float2*>(CtTwiddles<N>::table.w);
-        for (int i = threadIdx.x; i < TW; i += TT) lds[i] = src[i];
-    }
+    fetch(cur, pr);
+    stof_ct::stage_twiddles<N>(lds, threadIdx.x, TT);
     __syncthreads();
-    if (diag & 4) return;
     for (long long p0 = (long long)blockIdx.x * PPW; p0 < npairs; p0 += stride, pr += stride) {
         const bool active = pr < npairs;
         if (WPP == 1 && !active) break;                          // a lone wave: nobody waits for it
-        if (WPP > 1) __syncthreads();                             // previous pair fully read back
+        auto sync = [] { if (WPP > 1) __syncthreads(); else wave_lds_sync(); };
+        sync();                                                   // previous pair fully read back
         if (active) stof_io::stage_pair<IO, true>(Z, cur, N, tid, T);
-        if (WPP > 1) __syncthreads();
-        if (!(diag & 1)) analytic_ct<N, T>(Z, W, tid, [] { if (WPP > 1) __syncthreads(); });   // idle slots keep the barrier count
+        sync();
+        analytic_ct<N, T>(Z, W, tid, sync);                       // idle slots of a multi-wave group keep the barrier count
         if (!active) continue;
-        if (diag & 2) { if (Z[tid].x == 123.456f) env[tid] = 1.f; fetch(cur, pr + stride); continue; }
         const long long row = 2 * pr;
         const bool second = row + 1 < nrows;
         float* const e1 = env ? env + row * (size_t)N : nullptr;
@@ -432,7 +428,7 @@ int launch_ct(const float* x, int64_t nrows, float* env, float* re, float* im, i
     int64_t grid = (int64_t)ncu * (int64_t)((size_t)LDS_BYTES / lds);
     if (grid > groups) grid = groups;
     hipLaunchKernelGGL((hilbert_ct_kernel<N, WPP, PPW>), dim3((unsigned)grid), dim3(64 * WPP * PPW), lds, stream, x,
-                       (long long)nrows, env, re, im, getenv("STOF_HILBERT_DIAG") ? atoi(getenv("STOF_HILBERT_DIAG")) : 0);
+                       (long long)nrows, env, re, im);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
@@ -443,10 +439,12 @@ int try_launch_ct(const float* x, int64_t nrows, int64_t n, float* env, float* r
     for (const void* p : {(const void*)x, (const void*)env, (const void*)re, (const void*)im})
         if (reinterpret_cast<size_t>(p) & 15) return -1;        // 16-byte row accesses
     switch (n) {
-        case 1536: return mode == 2 ? launch_ct<1536, 2, 4>(x, nrows, env, re, im, ncu, stream)
-                                    : launch_ct<1536, 1, 4>(x, nrows, env, re, im, ncu, stream);
-        case 2000: return mode == 2 ? launch_ct<2000, 2, 4>(x, nrows, env, re, im, ncu, stream)
-                                    : launch_ct<2000, 1, 4>(x, nrows, env, re, im, ncu, stream);
+        // one wave per pair up to 2048 samples (16 register-resident 16-byte pieces per lane), two waves beyond
+        case 1536: return launch_ct<1536, 1, 4>(x, nrows, env, re, im, ncu, stream);
+        case 2000: return launch_ct<2000, 1, 4>(x, nrows, env, re, im, ncu, stream);
+        case 2048: return launch_ct<2048, 1, 4>(x, nrows, env, re, im, ncu, stream);
+        case 4000: return launch_ct<4000, 2, 2>(x, nrows, env, re, im, ncu, stream);
+        case 4096: return launch_ct<4096, 2, 2>(x, nrows, env, re, im, ncu, stream);
         default: return -1;
     }
 }

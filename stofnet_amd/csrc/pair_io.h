@@ -10,6 +10,7 @@
 namespace stof_io {
 
 using stof_fft::cf;
+typedef float4 __attribute__((may_alias)) f4a;      // 16-byte access to memory that is also read / written as cf or float
 
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
@@ -26,15 +27,15 @@ __device__ __forceinline__ void load_pair(cf* __restrict__ Z, const float* __res
                 const int q = q0 + k * T;
                 a[k] = b[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (q < nq) {
-                    a[k] = *reinterpret_cast<const float4*>(x1 + 4 * q);
-                    if (x2) b[k] = *reinterpret_cast<const float4*>(x2 + 4 * q);
+                    a[k] = *reinterpret_cast<const f4a*>(x1 + 4 * q);
+                    if (x2) b[k] = *reinterpret_cast<const f4a*>(x2 + 4 * q);
                 }
             }
 #pragma unroll
             for (int k = 0; k < IO_UNROLL; ++k) {
                 const int q = q0 + k * T;
                 if (q < nq) {
-                    float4* d = reinterpret_cast<float4*>(Z + 4 * q);
+                    f4a* d = reinterpret_cast<f4a*>(Z + 4 * q);
                     d[0] = make_float4(a[k].x, b[k].x, a[k].y, b[k].y);
                     d[1] = make_float4(a[k].z, b[k].z, a[k].w, b[k].w);
                 }
@@ -73,15 +74,15 @@ __device__ __forceinline__ void unmix_pair(const cf* __restrict__ Z, const float
                 const int q = q0 + k * T;
                 a[k] = b[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (q < nq) {
-                    a[k] = *reinterpret_cast<const float4*>(x1 + 4 * q);
-                    if (x2) b[k] = *reinterpret_cast<const float4*>(x2 + 4 * q);
+                    a[k] = *reinterpret_cast<const f4a*>(x1 + 4 * q);
+                    if (x2) b[k] = *reinterpret_cast<const f4a*>(x2 + 4 * q);
                 }
             }
 #pragma unroll
             for (int k = 0; k < IO_UNROLL; ++k) {
                 const int q = q0 + k * T;
                 if (q < nq) {
-                    const float4* s = reinterpret_cast<const float4*>(Z + 4 * q);
+                    const f4a* s = reinterpret_cast<const f4a*>(Z + 4 * q);
                     const float4 z0 = s[0], z1 = s[1];
                     const float xa[4] = {a[k].x, a[k].y, a[k].z, a[k].w}, xb[4] = {b[k].x, b[k].y, b[k].z, b[k].w};
                     const float re[4] = {z0.x, z0.z, z1.x, z1.z}, im[4] = {z0.y, z0.w, z1.y, z1.w};
@@ -119,8 +120,8 @@ __device__ __forceinline__ void load_pair_regs(PairRegs<IO>& r, const float* __r
         const int q = tid + k * T;
         r.a[k] = r.b[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < nq) {
-            r.a[k] = *reinterpret_cast<const float4*>(x1 + 4 * q);
-            if (x2) r.b[k] = *reinterpret_cast<const float4*>(x2 + 4 * q);
+            r.a[k] = *reinterpret_cast<const f4a*>(x1 + 4 * q);
+            if (x2) r.b[k] = *reinterpret_cast<const f4a*>(x2 + 4 * q);
         }
     }
 }
@@ -133,7 +134,7 @@ __device__ __forceinline__ void stage_pair(cf* __restrict__ Z, const PairRegs<IO
     for (int k = 0; k < IO; ++k) {
         const int q = tid + k * T;
         if (q < nq) {
-            float4* d = reinterpret_cast<float4*>(Z + (PADDED ? 4 * q + 2 * (q >> 2) : 4 * q));
+            f4a* d = reinterpret_cast<f4a*>(Z + (PADDED ? 4 * q + 2 * (q >> 2) : 4 * q));
             d[0] = make_float4(r.a[k].x, r.b[k].x, r.a[k].y, r.b[k].y);
             d[1] = make_float4(r.a[k].z, r.b[k].z, r.a[k].w, r.b[k].w);
         }
@@ -149,7 +150,7 @@ __device__ __forceinline__ void unmix_pair_regs(const cf* __restrict__ Z, const 
     for (int k = 0; k < IO; ++k) {
         const int q = tid + k * T;
         if (q < nq) {
-            const float4* s = reinterpret_cast<const float4*>(Z + (PADDED ? 4 * q + 2 * (q >> 2) : 4 * q));
+            const f4a* s = reinterpret_cast<const f4a*>(Z + (PADDED ? 4 * q + 2 * (q >> 2) : 4 * q));
             const float4 z0 = s[0], z1 = s[1];
             const float xa[4] = {r.a[k].x, r.a[k].y, r.a[k].z, r.a[k].w}, xb[4] = {r.b[k].x, r.b[k].y, r.b[k].z, r.b[k].w};
             const float re[4] = {z0.x, z0.z, z1.x, z1.z}, im[4] = {z0.y, z0.w, z1.y, z1.w};

@@ -390,6 +390,28 @@ def test_hilbert_more_lengths_vs_oracle(dev, n):
     assert np.abs(env - po.hilbert_envelope(x)).max() < ENV_TOL
 
 
+@pytest.mark.parametrize('n', [1536, 2000, 2048, 4000, 4096])
+@pytest.mark.parametrize('rows', [1, 2, 7, 1030])
+def test_hilbert_compile_time_plan_lengths(dev, n, rows):
+    """Row lengths served by the compile-time plans (hilbert_ct_kernel): odd batches leave a lone row in the last pair,
+    1030 rows = more pairs than one pass of the persistent grid's slots on a small grid; analytic signal and envelope
+    against the float64 oracle; an unaligned view must fall back to the run-time-plan kernel with the same result."""
+    from stofnet_amd import hilbert_transform
+    from stofnet_amd.hilbert import hilbert_envelope
+    x = synth.synth_randn(rows, n, seed=n + rows)[:, 0]
+    xd = torch.from_numpy(x).to(dev)
+    env = hilbert_envelope(xd).cpu().numpy()
+    want = po.hilbert_transform(x)
+    assert np.abs(env - np.abs(want)).max() < ENV_TOL
+    v = hilbert_transform(xd).cpu().numpy()
+    assert np.abs(v.real - want.real).max() < ENV_TOL and np.abs(v.imag - want.imag).max() < ENV_TOL
+    if rows == 7:
+        big = torch.zeros(rows * n + 1, device=dev)
+        big[1:] = xd.reshape(-1)
+        shifted = big[1:].view(rows, n)                      # 4-byte aligned rows only
+        assert np.abs(hilbert_envelope(shifted).cpu().numpy() - env).max() < ENV_TOL
+
+
 def test_hilbert_module_concat(dev):
     from stofnet_amd import HilbertTransform
     g = golden('f5_hilbert')

@@ -82,6 +82,9 @@ CASES = {
     'mask2coords_argmax_m20000': lambda: case_pick_sync(20000, None),
     'hilbert_4096x1536': lambda: case_hilbert(4096, 1536),
     'hilbert_4096x2000': lambda: case_hilbert(4096, 2000),
+    'hilbert_4096x2048': lambda: case_hilbert(4096, 2048),
+    'hilbert_4096x4000': lambda: case_hilbert(4096, 4000),
+    'hilbert_4096x4096': lambda: case_hilbert(4096, 4096),
     'hilbert_4096x8000': lambda: case_hilbert(4096, 8000),
     'hilbert_1024x20000': lambda: case_hilbert(1024, 20000),
     'hilbert_512x30720': lambda: case_hilbert(512, 30720),
