@@ -189,7 +189,10 @@ Config make_config(int64_t L, int32_t grad_step, int32_t radius, float threshold
     Config cf;
     cf.L = (int)L; cf.spacing = (float)grad_step; cf.radius = radius;
     cf.th_pos = threshold; cf.th_neg = -threshold / 4.0f;             // models/gradpeak.py:19
-    cf.ival_min = ival_min; cf.ival_max = ival_max; cf.cap = cap; cf.echo_max = echo_max > 0 ? echo_max : 0;
+    // the gate ival_min < am - ap < ival_max is evaluated in 32-bit arithmetic on positions below 2^30
+    cf.ival_min = ival_min < -(1 << 30) ? -(1 << 30) : ival_min;
+    cf.ival_max = ival_max > (1 << 30) ? (1 << 30) : ival_max;
+    cf.cap = cap; cf.echo_max = echo_max > 0 ? echo_max : 0;
     return cf;
 }
 

@@ -46,51 +46,59 @@ __host__ __device__ constexpr int ring_floats(int radius) { return 2 * ring_entr
 
 struct RowState {
     int last_ap = -1;          // most recent rising-slope edge seen so far (carry across words)
-    int last_kept_ap = -1;     // onset of the last surviving candidate (uniqueness, :58-59)
+    int done = 0;              // last_ap already has its peak (first am per distinct ap, :58-59)
     int nout = 0;
     int any_ap = 0, any_am = 0;
     unsigned long long P = 0, M = 0, V = 0;      // flags / validity of the previous word
 };
 
-__device__ __forceinline__ int msb64(unsigned long long v) { return 63 - __builtin_clzll(v); }
-
-// one word of the pairing: samples base .. base + 63, rising-slope edges EP, falling-slope edges EM
+// One word of the pairing: samples base .. base + 63, rising-slope edges EP, falling-slope edges EM (ballot words, so
+// everything here is wave-uniform and runs on the scalar unit).
+// Reference (:42-60): every falling-slope edge `am` takes the nearest rising-slope edge `ap` <= am, the gate keeps
+// ival_min < am - ap < ival_max, and per distinct ap the FIRST surviving am is kept.  Read from the ap side: an onset ap
+// owns the stretch [ap, next ap) and its peak is the first EM edge of that stretch inside the gate.  Noisy rows have a
+// falling-slope edge every dozen samples but only a few onsets, so the work is per onset, not per edge: a word without
+// a pending onset and without a new one costs one scalar test.  (The reference's 2**32 sentinel, :43 / Q8, maps a peak
+// without a preceding onset to the first onset; such a peak is dropped here as it is there for any ival_min >= 0.)
 template <class EnvAt>
 __device__ __forceinline__ void pair_word(RowState& st, int base, unsigned long long EP, unsigned long long EM, int lane,
                                           const Config& cf, float* __restrict__ out, EnvAt env_at) {
     st.any_ap |= (EP != 0);
     st.any_am |= (EM != 0);
-    if (EM == 0) {                                           // wave-uniform: nothing to pair in this word
-        if (EP) st.last_ap = base + msb64(EP);
-        return;
-    }
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const unsigned long long le_mask = lt_mask | (1ull << lane);
-    const int i = base + lane;
-    const bool em = (EM >> lane) & 1ull;
-    // nearest preceding (<=) onset candidate for this lane's peak candidate (:42-45); the reference's 2**32 sentinel
-    // (:43, Q8) maps a peak without a preceding onset to the first onset, which the gap gate then rejects (gap < 0)
-    const unsigned long long below = EP & le_mask;
-    const int ap = below ? (base + msb64(below)) : st.last_ap;
-    const int gap = i - ap;
-    const bool valid = em && (ap >= 0) && (gap > cf.ival_min) && (gap < cf.ival_max);     // :48-49
-    const unsigned long long vm = __ballot(valid);
-    const unsigned long long vbelow = vm & lt_mask;
-    const int prev_ap_lane = __shfl(ap, vbelow ? msb64(vbelow) : 0);
-    const int prev_ap = vbelow ? prev_ap_lane : st.last_kept_ap;
-    const bool keep = valid && (ap != prev_ap);              // first am per distinct ap (:58-59)
-    const unsigned long long km = __ballot(keep);
-    if (keep) {
-        const long long pos = st.nout + __builtin_popcountll(km & lt_mask);
-        if (pos < cf.cap) {
-            out[3 * pos + 0] = (float)ap;
-            out[3 * pos + 1] = (float)i;
-            out[3 * pos + 2] = env_at(i);                    // data[i, am] (:66)
+    if (EP == 0 && (st.last_ap < 0 || st.done)) return;
+    unsigned long long ep = EP;
+    int lo = 0;                                              // the pending onset owns bits [lo, next onset)
+    while (true) {
+        const int p = ep ? __builtin_ctzll(ep) : 64;
+        if (st.last_ap >= 0 && !st.done) {
+            // (32-bit arithmetic: positions are below 2^30 and the host clamps the gate to +-2^30)
+            int a = st.last_ap + cf.ival_min + 1 - base;      // first bit inside the gate
+            int b = st.last_ap + cf.ival_max - base;          // one past the last bit inside the gate
+            if (a < lo) a = lo;
+            if (b > p) b = p;
+            if (a < b) {
+                const unsigned long long upto_b = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
+                const unsigned long long m = EM & upto_b & ~((1ull << a) - 1ull);
+                if (m) {
+                    const int am = base + __builtin_ctzll(m);
+                    if (st.nout < cf.cap && lane == 0) {
+                        float* o = out + 3ll * st.nout;
+                        o[0] = (float)st.last_ap;
+                        o[1] = (float)am;
+                        o[2] = env_at(am);                   // data[i, am] (:66)
+                    }
+                    st.nout += 1;
+                    st.done = 1;
+                }
+            }
+            if (base + 63 >= st.last_ap + cf.ival_max - 1) st.done |= (p == 64);      // gate closed
         }
+        if (p == 64) break;
+        st.last_ap = base + p;
+        st.done = 0;
+        lo = p;
+        ep &= ep - 1ull;
     }
-    st.nout += __builtin_popcountll(km);
-    if (vm) st.last_kept_ap = __shfl(ap, msb64(vm));
-    if (EP) st.last_ap = base + msb64(EP);
 }
 
 // Streams NR rows (NR = 1, or 2 rows whose samples arrive together) through gradient -> blur -> flags -> pairing.
