@@ -241,7 +241,9 @@ template <int A, int B> struct BfComposite {
 template <> struct Bf<6> { static STOF_HD void run(cf (&x)[6]) { BfComposite<2, 3>::run(x); } };
 template <> struct Bf<10> { static STOF_HD void run(cf (&x)[10]) { BfComposite<2, 5>::run(x); } };
 template <> struct Bf<8> { static STOF_HD void run(cf (&x)[8]) { BfComposite<2, 4>::run(x); } };
+template <> struct Bf<15> { static STOF_HD void run(cf (&x)[15]) { BfComposite<3, 5>::run(x); } };
 template <> struct Bf<16> { static STOF_HD void run(cf (&x)[16]) { BfComposite<4, 4>::run(x); } };
+template <> struct Bf<20> { static STOF_HD void run(cf (&x)[20]) { BfComposite<4, 5>::run(x); } };
 template <> struct Bf<25> { static STOF_HD void run(cf (&x)[25]) { BfComposite<5, 5>::run(x); } };
 
 // ---- plan ---------------------------------------------------------------------------------------------------------
@@ -549,11 +551,20 @@ STOF_HD void ct_pass(cf* __restrict__ Z, const cf* __restrict__ W, int tid) {
 // samples whose DFT_16 gives the frequencies k = k_low(b) + q N/16, q = 0..15, with k_low(b) = 0 iff b = 0.  Filter
 // (utils/hilbert.py:13-17 with the inverse transform's 1/N): q < 8 -> 2/N (1/N at k = 0), q = 8 -> 1/N at the Nyquist
 // bin (b = 0) else 0, q > 8 -> 0; then the inverse DFT_16.
+// CtFilter: the scale of bins below Nyquist (`two`), of the DC and Nyquist bins (`one`), and whether this transform holds
+// those two bins at all (`edge`).  A stand-alone transform of length N uses {1/N, 2/N, true}; the inner blocks of a
+// four-step transform of length R0 * N hold the frequencies q + R0 k, so block q != 0 has neither DC nor Nyquist and all
+// blocks scale by the full length.
+struct CtFilter { float one, two; bool edge; };
+template <int N> STOF_HD CtFilter ct_filter_default() {
+    CtFilter f; f.one = (float)(1.0 / (double)N); f.two = (float)(2.0 / (double)N); f.edge = true; return f;
+}
+
 template <int N, int T>
-STOF_HD void ct_middle16(cf* __restrict__ Z, int tid) {
+STOF_HD void ct_middle16(cf* __restrict__ Z, int tid, const CtFilter filt) {
     constexpr int NB = N / 16, ITERS = (NB + T - 1) / T;
     constexpr bool RAGGED = (NB % T) != 0;
-    constexpr float one = (float)(1.0 / (double)N), two = (float)(2.0 / (double)N);
+    const float one = filt.one, two = filt.two;
     auto load = [&](auto& G, auto gc) {
         constexpr int g = decltype(gc)::value;
         const unsigned b = (unsigned)(tid + g * T);
@@ -563,7 +574,7 @@ STOF_HD void ct_middle16(cf* __restrict__ Z, int tid) {
         for (int k = 0; k < 16; ++k) G.x[0][k] = Z[G.off[0] + k];
     };
     auto finish = [&](auto& G) {
-        const bool first = (G.off[0] == 0);
+        const bool first = (G.off[0] == 0) && filt.edge;
         Bf<16>::run(G.x[0]);
         G.x[0][0] = cscale(G.x[0][0], first ? one : two);
 #pragma unroll
@@ -582,27 +593,31 @@ STOF_HD void ct_middle16(cf* __restrict__ Z, int tid) {
 
 // forward passes on the way down, the middle pass at the bottom, the inverse passes (reverse order) on the way up
 template <int N, int T, int S, int M, class Sync>
-STOF_HD void ct_level(cf* __restrict__ Z, const cf* __restrict__ W, int tid, Sync& sync) {
+STOF_HD void ct_level(cf* __restrict__ Z, const cf* __restrict__ W, int tid, Sync& sync, const CtFilter& filt) {
     constexpr CtPlan P = ct_plan_for(N);
     static_assert(P.npass >= 0, "no compile-time plan for this length");
     if constexpr (S < P.npass) {
         constexpr int R = P.radix[S];
         ct_pass<N, M, R, false, T>(Z, W, tid);
         sync();
-        ct_level<N, T, S + 1, M / R>(Z, W, tid, sync);
+        ct_level<N, T, S + 1, M / R>(Z, W, tid, sync, filt);
         ct_pass<N, M, R, true, T>(Z, W, tid);
         sync();
     } else {
         static_assert(M == 16, "the middle pass takes the last 16 values");
-        ct_middle16<N, T>(Z, tid);
+        ct_middle16<N, T>(Z, tid, filt);
         sync();
     }
 }
 
 // analytic signal of the N complex values in the padded slot Z, in place, by T threads (tid < T)
 template <int N, int T, class Sync>
+STOF_HD void analytic_ct(cf* __restrict__ Z, const cf* __restrict__ W, int tid, Sync sync, const CtFilter filt) {
+    ct_level<N, T, 0, N>(Z, W, tid, sync, filt);
+}
+template <int N, int T, class Sync>
 STOF_HD void analytic_ct(cf* __restrict__ Z, const cf* __restrict__ W, int tid, Sync sync) {
-    ct_level<N, T, 0, N>(Z, W, tid, sync);
+    analytic_ct<N, T>(Z, W, tid, sync, ct_filter_default<N>());
 }
 
 }  // namespace stof_fft

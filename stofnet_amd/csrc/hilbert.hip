@@ -449,6 +449,213 @@ int try_launch_ct(const float* x, int64_t nrows, int64_t n, float* env, float* r
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Rows beyond LDS whose length factors as n = R0 * M with M a compile-time-plan length: four-step transform.
+//   outer_forward_kernel<R0>    thread j: z_k = (x1, x2)[j + M k], y = DFT_R0(z), y_q *= w_n^{j q}  -> scratch[pair][q][j]
+//   hilbert_ct_blocks_kernel<M> every block (pair, q) is one length-M analytic_ct in LDS: DFT_M(y_q)[k'] is the frequency
+//                               q + R0 k', so the block filters with the full length's scales and only block 0 holds the
+//                               DC and Nyquist bins (CtFilter)
+//   outer_inverse_kernel<R0>    thread j: y_q conj(w_n^{j q}), inverse DFT_R0 -> analytic pair at j + M k; un-mixing with
+//                               the rows and envelope / re / im stores
+// The scratch (8 n bytes per pair) lives in the workspace; rows are processed in chunks of <= FOURSTEP_CHUNK_BYTES of
+// scratch so that it stays in the 256 MB Infinity Cache between the three kernels.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr size_t FOURSTEP_CHUNK_BYTES = 64u << 20;
+
+__global__ void outer_table_kernel(float2* __restrict__ tw, int M, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    double s, c;
+    sincospi(-2.0 * (double)j / (double)n, &s, &c);
+    tw[j] = make_float2((float)c, (float)s);
+}
+
+// w[q] = w1^q, q = 1 .. R-1 (w^2q = (w^q)^2, w^(2q+1) = w^2q w)
+template <int R>
+__device__ __forceinline__ void twiddle_powers(stof_fft::cf w1, stof_fft::cf (&w)[R]) {
+    using namespace stof_fft;
+    w[1] = w1;
+    static_for<R>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q >= 2) w[q] = (q % 2 == 0) ? stof_fft::cmul(w[q / 2], w[q / 2]) : stof_fft::cmul(w[q - 1], w[1]);
+    });
+}
+
+template <int R0>
+__global__ __launch_bounds__(256) void outer_forward_kernel(const float* __restrict__ x, long long nrows, long long pair0, int M,
+                                                            const float2* __restrict__ twn, float2* __restrict__ scratch) {
+    using namespace stof_fft;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const long long pair = blockIdx.y, row = 2 * (pair0 + pair);
+    const size_t n = (size_t)R0 * M;
+    const float* x1 = x + row * n;
+    const float* x2 = row + 1 < nrows ? x1 + n : nullptr;
+    cf z[R0];
+#pragma unroll
+    for (int k = 0; k < R0; ++k) z[k] = mk(x1[j + (size_t)M * k], x2 ? x2[j + (size_t)M * k] : 0.f);
+    Bf<R0>::run(z);
+    cf w[R0];
+    const float2 t = twn[j];
+    twiddle_powers<R0>(mk(t.x, t.y), w);
+    float2* out = scratch + (size_t)pair * n + j;
+    out[0] = make_float2(z[0].x, z[0].y);
+#pragma unroll
+    for (int q = 1; q < R0; ++q) {
+        const cf v = stof_fft::cmul(z[q], w[q]);
+        out[(size_t)q * M] = make_float2(v.x, v.y);
+    }
+}
+
+template <int R0>
+__global__ __launch_bounds__(256) void outer_inverse_kernel(const float* __restrict__ x, long long nrows, long long pair0, int M,
+                                                            const float2* __restrict__ twn, const float2* __restrict__ scratch,
+                                                            float* __restrict__ env, float* __restrict__ re, float* __restrict__ im) {
+    using namespace stof_fft;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const long long pair = blockIdx.y, row = 2 * (pair0 + pair);
+    const size_t n = (size_t)R0 * M;
+    const bool second = row + 1 < nrows;
+    const float* x1 = x + row * n;
+    const float* x2 = second ? x1 + n : nullptr;
+    const float2* in = scratch + (size_t)pair * n + j;
+    cf y[R0], w[R0];
+    const float2 t = twn[j];
+    twiddle_powers<R0>(mk(t.x, t.y), w);
+#pragma unroll
+    for (int q = 0; q < R0; ++q) {
+        const float2 v = in[(size_t)q * M];
+        y[q] = q ? stof_fft::cmulc(mk(v.x, v.y), w[q]) : mk(v.x, v.y);
+    }
+    Bf<R0>::run(y);                                               // inverse DFT = forward, outputs reversed
+#pragma unroll
+    for (int k = 0; k < R0; ++k) {
+        const cf z = y[(R0 - k) % R0];
+        const size_t i = j + (size_t)M * k;
+        const float a = x1[i], b = x2 ? x2[i] : 0.f;
+        const float v1 = z.y - b, v2 = a - z.x;                   // pair un-mixing (see hilbert_pairs_kernel)
+        if (env) { env[row * n + i] = stof_io::envelope(a, v1); if (second) env[(row + 1) * n + i] = stof_io::envelope(b, v2); }
+        if (re) { re[row * n + i] = a; if (second) re[(row + 1) * n + i] = b; }
+        if (im) { im[row * n + i] = v1; if (second) im[(row + 1) * n + i] = v2; }
+    }
+}
+
+template <int M, int WPP, int PPW>
+__global__ __launch_bounds__(64 * WPP * PPW) void hilbert_ct_blocks_kernel(float2* __restrict__ blocks, long long nblocks, int R0,
+                                                                            float inv_n) {
+    using namespace stof_fft;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    constexpr int T = 64 * WPP, TT = T * PPW;
+    constexpr int TWP = stof_ct::twiddle_lds_entries<M>(), SLOT = ct_slot_entries(M);
+    cf* const W = reinterpret_cast<cf*>(lds);
+    const int slot = threadIdx.x / T, tid = threadIdx.x % T;
+    cf* const Z = W + TWP + slot * SLOT;
+    stof_ct::stage_twiddles<M>(lds, threadIdx.x, TT);
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * PPW;
+    auto sync = [] { if (WPP > 1) __syncthreads(); else wave_lds_sync(); };
+    for (long long b0 = (long long)blockIdx.x * PPW; b0 < nblocks; b0 += stride) {
+        const long long b = b0 + slot;
+        const bool active = b < nblocks;
+        if (WPP == 1 && !active) break;
+        stof_io::f4a* const blk = reinterpret_cast<stof_io::f4a*>(blocks + (active ? b : 0) * (long long)M);
+        sync();
+        if (active) {
+            for (int i = tid; i < M / 2; i += T)                  // two complex values per 16-byte piece; 2 i is even, so the
+                *reinterpret_cast<stof_io::f4a*>(Z + 2 * i + 2 * (i >> 3)) = blk[i];      // pair stays inside its 16-block
+        }
+        sync();
+        CtFilter filt;
+        filt.one = inv_n; filt.two = 2.0f * inv_n; filt.edge = (b % R0) == 0;
+        analytic_ct<M, T>(Z, W, tid, sync, filt);
+        if (active) {
+            for (int i = tid; i < M / 2; i += T) blk[i] = *reinterpret_cast<const stof_io::f4a*>(Z + 2 * i + 2 * (i >> 3));
+        }
+    }
+}
+
+struct FourStepPlan { int R0, M; };
+bool four_step_plan(int64_t n, FourStepPlan* p) {
+    static const int ms[5] = {4096, 4000, 2048, 2000, 1536};
+    static const int rs[10] = {2, 3, 4, 5, 6, 8, 10, 15, 16, 20};
+    for (int m : ms) {
+        if (n % m) continue;
+        const int64_t r = n / m;
+        for (int c : rs) if (r == c) { p->R0 = c; p->M = m; return true; }
+    }
+    return false;
+}
+int64_t four_step_chunk_pairs(int64_t n) {
+    const int64_t c = (int64_t)(FOURSTEP_CHUNK_BYTES / ((size_t)n * sizeof(float2)));
+    return c < 1 ? 1 : c;
+}
+
+template <int M, int WPP, int PPW>
+int launch_blocks(float2* blocks, int64_t nblocks, int R0, float inv_n, int ncu, hipStream_t stream) {
+    constexpr size_t lds = ((size_t)stof_ct::twiddle_lds_entries<M>() + (size_t)PPW * stof_fft::ct_slot_entries(M)) * sizeof(float2);
+    static stof::LdsLimitOnce once;
+    if (int st = once.ensure(reinterpret_cast<const void*>(&hilbert_ct_blocks_kernel<M, WPP, PPW>), LDS_BYTES)) return st;
+    const int64_t groups = (nblocks + PPW - 1) / PPW;
+    int64_t grid = (int64_t)ncu * (int64_t)((size_t)LDS_BYTES / lds);
+    if (grid > groups) grid = groups;
+    hipLaunchKernelGGL((hilbert_ct_blocks_kernel<M, WPP, PPW>), dim3((unsigned)grid), dim3(64 * WPP * PPW), lds, stream, blocks,
+                       (long long)nblocks, R0, inv_n);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+template <int R0>
+void launch_outer(bool inverse, const float* x, int64_t nrows, int64_t pair0, int64_t npairs, int M, const float2* twn,
+                  float2* scratch, float* env, float* re, float* im, hipStream_t stream) {
+    const dim3 grid((unsigned)((M + 255) / 256), (unsigned)npairs);
+    if (inverse)
+        hipLaunchKernelGGL(outer_inverse_kernel<R0>, grid, dim3(256), 0, stream, x, (long long)nrows, (long long)pair0, M, twn,
+                           (const float2*)scratch, env, re, im);
+    else
+        hipLaunchKernelGGL(outer_forward_kernel<R0>, grid, dim3(256), 0, stream, x, (long long)nrows, (long long)pair0, M, twn, scratch);
+}
+
+// the workspace holds w_n^j (j < M) followed by the scratch of one chunk of pairs
+int run_four_step(const FourStepPlan& fp, const float* x, int64_t nrows, int64_t n, float* env, float* re, float* im,
+                  void* workspace, int ncu, hipStream_t stream) {
+    float2* twn = static_cast<float2*>(workspace);
+    float2* scratch = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + ((size_t)fp.M * sizeof(float2) + 255) / 256 * 256);
+    hipLaunchKernelGGL(outer_table_kernel, dim3((unsigned)((fp.M + 255) / 256)), dim3(256), 0, stream, twn, fp.M, (int)n);
+    const int64_t npairs = (nrows + 1) / 2, chunk = four_step_chunk_pairs(n);
+    const float inv_n = (float)(1.0 / (double)n);
+    for (int64_t p0 = 0; p0 < npairs; p0 += chunk) {
+        const int64_t np = npairs - p0 < chunk ? npairs - p0 : chunk;
+        for (int pass = 0; pass < 3; ++pass) {
+            if (pass == 1) {
+                int st;
+                switch (fp.M) {
+                    case 1536: st = launch_blocks<1536, 1, 4>(scratch, np * fp.R0, fp.R0, inv_n, ncu, stream); break;
+                    case 2000: st = launch_blocks<2000, 1, 4>(scratch, np * fp.R0, fp.R0, inv_n, ncu, stream); break;
+                    case 2048: st = launch_blocks<2048, 1, 4>(scratch, np * fp.R0, fp.R0, inv_n, ncu, stream); break;
+                    case 4000: st = launch_blocks<4000, 2, 2>(scratch, np * fp.R0, fp.R0, inv_n, ncu, stream); break;
+                    default: st = launch_blocks<4096, 2, 2>(scratch, np * fp.R0, fp.R0, inv_n, ncu, stream); break;
+                }
+                if (st != STOF_OK) return st;
+                continue;
+            }
+            const bool inv = pass == 2;
+            switch (fp.R0) {
+                case 2: launch_outer<2>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
+                case 3: launch_outer<3>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
+                case 4: launch_outer<4>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
+                case 5: launch_outer<5>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
+                case 6: launch_outer<6>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
+                case 8: launch_outer<8>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
+                case 10: launch_outer<10>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
+                case 15: launch_outer<15>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
+                case 16: launch_outer<16>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
+                default: launch_outer<20>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
+            }
+        }
+    }
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
 }  // namespace
 
 namespace stof {
@@ -473,6 +680,13 @@ extern "C" size_t stof_hilbert_workspace_bytes(int64_t N, int64_t n) {
         const int64_t units = (n % 2 == 0) ? (N + 1) / 2 : N;
         const int64_t grid = units < GENERIC_ZG_GRID ? units : GENERIC_ZG_GRID;
         bytes += (size_t)grid * 2 * (size_t)n * sizeof(float2);
+    }
+    FourStepPlan fsp;
+    if (n % 2 == 0 && four_step_plan(n, &fsp)) {                   // n = R0 * M: twiddle table + the scratch of one chunk of pairs
+        const int64_t npairs = (N + 1) / 2, chunk = four_step_chunk_pairs(n);
+        const size_t fs = ((size_t)fsp.M * sizeof(float2) + 255) / 256 * 256 +
+                          (size_t)(npairs < chunk ? npairs : chunk) * (size_t)n * sizeof(float2) + 256;
+        if (fs > bytes) bytes = fs;                                // (the generic kernels remain the fallback for unaligned rows)
     }
     return bytes;
 }
@@ -509,6 +723,15 @@ extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, fl
         return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
     }
 
+    {
+        static const int fs_mode = [] { const char* e = getenv("STOF_HILBERT_FOURSTEP"); return e ? atoi(e) : 1; }();
+        FourStepPlan fsp;
+        bool aligned = true;
+        for (const void* p : {(const void*)x, (const void*)env, (const void*)re, (const void*)im, (const void*)workspace})
+            aligned = aligned && !(reinterpret_cast<size_t>(p) & 15);
+        if (fs_mode && aligned && n % 2 == 0 && four_step_plan(n, &fsp))
+            return run_four_step(fsp, x, N, n, env, re, im, workspace, ncu, stream);
+    }
     FftPlan plan;
     make_plan((int)n, &plan);
     const size_t data_lds = (size_t)n * sizeof(float2) * (plan.needs_second ? 2 : 1);

@@ -55,7 +55,9 @@ extern "C" int fft_butterfly(int R, float* z) {
         case 6: Bf<6>::run(*reinterpret_cast<cf(*)[6]>(x)); return 1;
         case 8: Bf<8>::run(*reinterpret_cast<cf(*)[8]>(x)); return 1;
         case 10: Bf<10>::run(*reinterpret_cast<cf(*)[10]>(x)); return 1;
+        case 15: Bf<15>::run(*reinterpret_cast<cf(*)[15]>(x)); return 1;
         case 16: Bf<16>::run(*reinterpret_cast<cf(*)[16]>(x)); return 1;
+        case 20: Bf<20>::run(*reinterpret_cast<cf(*)[20]>(x)); return 1;
         case 25: Bf<25>::run(*reinterpret_cast<cf(*)[25]>(x)); return 1;
     }
     return 0;
@@ -71,7 +73,7 @@ static void host_level(cf* Z, const cf* W) {
         host_level<N, T, S + 1, M / R>(Z, W);
         for (int tid = 0; tid < T; ++tid) ct_pass<N, M, R, true, T>(Z, W, tid);
     } else {
-        for (int tid = 0; tid < T; ++tid) ct_middle16<N, T>(Z, tid);
+        for (int tid = 0; tid < T; ++tid) ct_middle16<N, T>(Z, tid, ct_filter_default<N>());
     }
 }
 

@@ -35,7 +35,7 @@ def plan(lib, n):
     return list(r[:k])
 
 
-@pytest.mark.parametrize('R', [2, 3, 4, 5, 6, 8, 10, 16, 25])
+@pytest.mark.parametrize('R', [2, 3, 4, 5, 6, 8, 10, 15, 16, 20, 25])
 def test_butterflies_match_numpy_dft(harness, R):
     rng = np.random.default_rng(R)
     z = (rng.standard_normal(R) + 1j * rng.standard_normal(R)).astype(np.complex64)

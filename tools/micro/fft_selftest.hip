@@ -88,7 +88,7 @@ static void host_level(cf* Z, const cf* W) {
         host_level<N, T, S + 1, M / R>(Z, W);
         for (int tid = 0; tid < T; ++tid) ct_pass<N, M, R, true, T>(Z, W, tid);
     } else {
-        for (int tid = 0; tid < T; ++tid) ct_middle16<N, T>(Z, tid);
+        for (int tid = 0; tid < T; ++tid) ct_middle16<N, T>(Z, tid, ct_filter_default<N>());
     }
 }
 
