@@ -72,6 +72,158 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void gradpeak_rows_kernel(const fl
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// grad_peak_detect on envelope rows in HBM, work-group of 4 waves: each row is streamed by W = 1, 2 or 4 waves that
+// split its iterations (a wave refills its gradient ring by running warm_words extra iterations), so few long rows
+// still fill the chip.  The envelope reaches the streaming loop through LDS: a wave copies SPLIT_CHUNK + 1 words of
+// its stretch with coalesced loads that are in flight together (the next chunk is requested before the current one is
+// streamed), instead of waiting for one HBM round trip per 64 samples.  The flag words of the row go to LDS; after a
+// barrier the first wave of the row pairs them (pair_stored_words).  MOMENTS: the sums of the default threshold (Q7).
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int SPLIT_CHUNK = 8;                                   // iterations per LDS chunk
+constexpr int SPLIT_BUF = (SPLIT_CHUNK + 1) * 64 + 2;            // floats of the chunk buffer: one sample before, one word + one sample after
+__host__ __device__ inline int split_wave_floats(int radius) { return stof_gp::ring_floats(radius) + SPLIT_BUF; }
+__host__ __device__ inline int split_flag_offset(int radius) {   // floats before the flag words (8-byte aligned)
+    const int f = stof_gp::TAPS_LDS + 4 * split_wave_floats(radius);
+    return f + (f & 1);
+}
+inline size_t split_lds_bytes(int L, int radius, int W) {
+    return (size_t)split_flag_offset(radius) * 4 + (size_t)(4 / W) * 3 * stof_gp::word_count(L, radius) * 8;
+}
+
+template <bool MOMENTS>
+__global__ __launch_bounds__(256) void gradpeak_split_kernel(const float* __restrict__ env, long long N, Config cf,
+                                                             const float* __restrict__ taps, const float* __restrict__ th_dev,
+                                                             float* __restrict__ echoes, float* __restrict__ reduced,
+                                                             int* __restrict__ counts, int* __restrict__ flags,
+                                                             double* __restrict__ stats, int W) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = cf.L, rad = cf.radius, nwords = stof_gp::word_count(L, rad), RPW = 4 / W;
+    float* const tp = lds_f;
+    float* const ring = tp + stof_gp::TAPS_LDS + wave * split_wave_floats(rad);
+    float* const buf = ring + stof_gp::ring_floats(rad);
+    stof_gp::stage_taps(tp, taps, rad, tid, 256);
+    if (th_dev != nullptr) {                                   // default threshold computed on the device (Q7)
+        cf.th_pos = *th_dev;
+        cf.th_neg = -cf.th_pos / 4.0f;                          // models/gradpeak.py:19
+    }
+    const int slot = wave / W, part = wave % W;                  // row slot of this wave, its share of the row's iterations
+    unsigned long long* const F = reinterpret_cast<unsigned long long*>(tp + split_flag_offset(rad)) + (size_t)slot * 3 * nwords;
+    // iterations [p_first, p_last] of this wave (contiguous, near-equal shares); the stream starts warm_words earlier
+    const int per = (nwords + W - 1) / W, p_first = part * per, p_last = (p_first + per < nwords ? p_first + per : nwords) - 1;
+    int s_first = p_first - stof_gp::warm_words(rad);
+    if (s_first < 0) s_first = 0;
+    double mom[2] = {0.0, 0.0};
+    __syncthreads();
+    for (long long row0 = (long long)blockIdx.x * RPW; row0 < N; row0 += (long long)gridDim.x * RPW) {
+        const long long row = row0 + slot;
+        if (row < N && p_first <= p_last) {
+            const float* e = env + row * (long long)L;
+            float nxt[SPLIT_CHUNK + 2];
+            // the chunk of the iterations c0 .. c0 + SPLIT_CHUNK - 1 holds the samples 64 c0 - 1 .. 64 (c0 + SPLIT_CHUNK + 1):
+            // one sample before (central difference of the first sample), one word + one sample after (the stream fetches
+            // one iteration ahead)
+            auto request = [&](int c0) {
+#pragma unroll
+                for (int k = 0; k < SPLIT_CHUNK + 2; ++k) {
+                    int sidx = 64 * c0 - 1 + 64 * k + lane;
+                    sidx = sidx < 0 ? 0 : (sidx > L - 1 ? L - 1 : sidx);
+                    nxt[k] = (k < SPLIT_CHUNK + 1 || lane < 2) ? e[sidx] : 0.f;
+                }
+            };
+            request(s_first);
+            for (int c0 = s_first; c0 <= p_last; c0 += SPLIT_CHUNK) {
+                stof_fft::wave_lds_sync();                        // the previous chunk has been streamed
+#pragma unroll
+                for (int k = 0; k < SPLIT_CHUNK + 1; ++k) buf[64 * k + lane] = nxt[k];
+                if (lane < 2) buf[64 * (SPLIT_CHUNK + 1) + lane] = nxt[SPLIT_CHUNK + 1];
+                stof_fft::wave_lds_sync();
+                if (c0 + SPLIT_CHUNK <= p_last) request(c0 + SPLIT_CHUNK);       // in flight while this chunk is streamed
+                const int c1 = c0 + SPLIT_CHUNK - 1 < p_last ? c0 + SPLIT_CHUNK - 1 : p_last;
+                const int base = 64 * c0 - 1;
+                stof_gp::stream_words<1>(
+                    cf, tp, ring, lane,
+                    [&](int u, float (&v)[1]) { const int j = u - base; v[0] = buf[j < 0 ? 0 : j]; },   // (j < 0 only for masked samples)
+                    c0, c1, c0 == s_first,
+                    [&](int c, int, unsigned long long P, unsigned long long M, unsigned long long V, float sm) {
+                        if (c < p_first) return;                  // refilling the ring
+                        if (MOMENTS) {
+                            mom[0] += (double)sm;
+                            mom[1] += (double)sm * (double)sm;
+                        } else if (lane == 0) {
+                            F[3 * c] = P; F[3 * c + 1] = M; F[3 * c + 2] = V;
+                        }
+                    });
+            }
+        }
+        if (!MOMENTS) {
+            __syncthreads();                                      // the row's flag words are complete
+            if (row < N && part == 0) {
+                float* const out = echoes + row * cf.cap * 3;
+                RowState st;
+                const float* e = env + row * (long long)L;
+                stof_gp::pair_stored_words(st, F, nwords, lane, cf, out, [&](int i) { return e[i]; });
+                stof_gp::finish_row(st, cf, row, out, reduced, counts, flags, lane);
+            }
+            __syncthreads();                                      // before the next rows overwrite the flag words
+        }
+    }
+    if (MOMENTS) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mom[0] += __shfl_xor(mom[0], o);
+            mom[1] += __shfl_xor(mom[1], o);
+        }
+        double* const red = reinterpret_cast<double*>(tp + split_flag_offset(rad));      // the flag words are unused in this mode
+        if (lane == 0) { red[wave] = mom[0]; red[4 + wave] = mom[1]; }
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < 4; ++w) { a += red[w]; b += red[4 + w]; }
+            atomicAdd(&stats[0], a);
+            atomicAdd(&stats[1], b);
+        }
+    }
+}
+
+// waves per row: one while the rows alone fill the chip (16 waves per CU), more for fewer rows
+int split_waves_per_row(int64_t N, int ncu) {
+    if (N >= (int64_t)ncu * 12) return 1;
+    if (N >= (int64_t)ncu * 6) return 2;
+    return 4;
+}
+
+// launches the split kernel if its LDS fits; false: the caller uses gradpeak_rows_kernel
+template <bool MOMENTS>
+bool launch_split(const float* env, int64_t N, const Config& cf, const float* taps, const float* th_dev, float* echoes,
+                  float* reduced, int* counts, int* flags, double* stats, hipStream_t stream, int* status) {
+    // STOF_GP_SPLIT (read per call: tests flip it): 0 = never, 1 / unset = by shape, 2 / 3 / 4 = always with 1 / 2 / 4 waves per row
+    const char* const e = getenv("STOF_GP_SPLIT");
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0) return false;
+    const int ncu = stof::device_cu_count();
+    // Measured on the MI355X: with enough rows to give every CU 12+ waves (one per row), gradpeak_rows_kernel is the
+    // faster one ([4096,2000]: 72 vs 88 us -- 16 waves per CU hide its per-word HBM latency and it has no barriers);
+    // few long rows are what this kernel is for ([512,30720]: 96 vs 278 us).
+    if (mode == 1 && N >= (int64_t)ncu * 12) return false;
+    int W = mode > 1 ? (mode == 2 ? 1 : (mode == 3 ? 2 : 4)) : split_waves_per_row(N, ncu);
+    size_t lds = split_lds_bytes(cf.L, cf.radius, W);
+    while (lds > (size_t)LDS_BYTES && W < 4) { W *= 2; lds = split_lds_bytes(cf.L, cf.radius, W); }
+    if (lds > (size_t)LDS_BYTES) return false;
+    static stof::LdsLimitOnce once;
+    if (int st = once.ensure(reinterpret_cast<const void*>(&gradpeak_split_kernel<MOMENTS>), LDS_BYTES)) { *status = st; return true; }
+    const int RPW = 4 / W;
+    int64_t grid = (N + RPW - 1) / RPW;
+    int64_t per_cu = (int64_t)((size_t)LDS_BYTES / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (grid > (int64_t)ncu * per_cu) grid = (int64_t)ncu * per_cu;
+    hipLaunchKernelGGL(gradpeak_split_kernel<MOMENTS>, dim3((unsigned)grid), dim3(256), lds, stream, env, (long long)N, cf, taps,
+                       th_dev, echoes, reduced, counts, flags, stats, W);
+    *status = hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+    return true;
+}
+
 // thres_pos = (grad_data.std() ** 16) * 1.2e13 (models/gradpeak.py:18): unbiased std of all N * L smoothed gradients
 // from stats = (sum, sum of squares, count), rounded to fp32 where torch rounds (std is an fp32 tensor, the power and
 // the product are fp32 operations); the 16th power is taken in double and rounded once (= a correctly rounded powf).
@@ -204,6 +356,11 @@ extern "C" int stof_gradpeak_moments(const float* env, int64_t N, int64_t L, int
     if (N == 0 || L == 0) return STOF_OK;
     if (radius > stof_gp::MAXRAD || L > 0x3fffffffLL) return STOF_ERR_UNSUPPORTED;
     const Config cf = make_config(L, grad_step, radius, 0.f, 0, 0, 0, 0);
+    {
+        int st = STOF_OK;
+        if (launch_split<true>(env, N, cf, taps, nullptr, nullptr, nullptr, nullptr, nullptr, stats, static_cast<hipStream_t>(stream), &st))
+            return st;
+    }
     int64_t grid = (N + ROWS_WAVES - 1) / ROWS_WAVES;
     const int64_t maxg = (int64_t)stof::device_cu_count() * 8;
     if (grid > maxg) grid = maxg;
@@ -230,6 +387,11 @@ extern "C" int stof_grad_peak_detect(const float* env, int64_t N, int64_t L, int
     if (radius > stof_gp::MAXRAD || L > 0x3fffffffLL || N > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
     const Config cf = make_config(L, grad_step, radius, threshold, ival_min, ival_max, cap, echo_max);
     if (hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return STOF_ERR_HIP;
+    {
+        int st = STOF_OK;
+        if (launch_split<false>(env, N, cf, taps, threshold_dev, echoes, reduced, counts, flags, nullptr, static_cast<hipStream_t>(stream), &st))
+            return st;
+    }
     int64_t grid = (N + ROWS_WAVES - 1) / ROWS_WAVES;
     const int64_t maxg = (int64_t)stof::device_cu_count() * 8;
     if (grid > maxg) grid = maxg;

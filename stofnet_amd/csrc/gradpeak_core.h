@@ -101,26 +101,34 @@ __device__ __forceinline__ void pair_word(RowState& st, int base, unsigned long 
     }
 }
 
-// Streams NR rows (NR = 1, or 2 rows whose samples arrive together) through gradient -> blur -> flags -> pairing.
+// Streams NR rows (NR = 1, or 2 rows whose samples arrive together) through gradient -> blur -> flags, one iteration per
+// 64 samples.  Iteration c handles the gradient of sample u = 64 c + lane and the blurred gradient / flags of sample
+// i = u - rad; the row has iterations 0 .. word_count(cf) - 1.
 //   env_pair(u, e)   : e[r] = envelope of row r at sample u, 0 <= u < L
-//   env_at(r, i)     : envelope of row r at sample i (amplitude of a kept peak)
 //   ring             : LDS, NR * ring_floats(radius) floats owned by this wave
 //   taps             : LDS, 16-byte aligned, the 2 rad + 1 taps followed by zeros up to a multiple of 8 (TAPS_LDS floats)
-//   MOMENTS          : accumulate sum / sum of squares of the blurred gradient instead of pairing (Q7 pre-pass)
-template <int NR, bool MOMENTS, class EnvPair, class EnvAt>
-__device__ __forceinline__ void stream_rows(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring,
-                                            int lane, EnvPair env_pair, EnvAt env_at, float* const (&out)[NR],
-                                            RowState (&st)[NR], double (&mom)[2]) {
+//   [c_first, c_last]: iterations to run.  `zero_ring`: the ring holds nothing of this row yet and is zeroed (= the
+//                      blur's zero padding left of the row); otherwise the call continues a stream whose previous call
+//                      ended at c_first - 1.  A stream that starts inside a row must begin warm_words(rad) iterations
+//                      early and ignore what the sink receives for them (the ring is being refilled).
+//   sink(c, r, P, M, V, sm) : flags of iteration c, row r (P: grad > th_pos, M: grad < th_neg, V: sample is an edge
+//                      candidate 0 .. L-2; ballot words) and the lane's blurred gradient (valid where in_row)
+__host__ __device__ constexpr int word_count(int L, int rad) { return (L - 1 + rad) / 64 + 2; }   // incl. the flushing iteration
+__host__ __device__ constexpr int warm_words(int rad) { return (2 * rad + 63) / 64; }
+
+template <int NR, class EnvPair, class Sink>
+__device__ __forceinline__ void stream_words(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring, int lane,
+                                             EnvPair env_pair, int c_first, int c_last, bool zero_ring, Sink sink) {
     const int L = cf.L, rad = cf.radius;
     const int RG = ring_entries(rad), rmask = RG - 1;
     const float two_sp = 2.0f * cf.spacing;
-    // zero padding of the blur to the left of the row (:94): ring slots of the samples -2 rad .. -1
-    for (int q = lane; q < 2 * RG; q += 64) {
+    if (zero_ring) {
+        for (int q = lane; q < 2 * RG; q += 64) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) ring[r * 2 * RG + q] = 0.f;
+            for (int r = 0; r < NR; ++r) ring[r * 2 * RG + q] = 0.f;
+        }
     }
     stof_fft::wave_lds_sync();
-    const int cend = (L - 1 + rad) / 64 + 1;                  // one extra iteration flushes the last word
     // the two envelope samples behind a gradient are fetched one iteration ahead, so that rows streamed from HBM pay
     // the memory latency once and not once per 64 samples
     float ea[NR], eb[NR];
@@ -131,8 +139,8 @@ __device__ __forceinline__ void stream_rows(const Config& cf, const float* __res
         env_pair(ia, ea);
         env_pair(ib > 0 ? ib : 0, eb);
     };
-    fetch(lane);
-    for (int c = 0; c <= cend; ++c) {
+    fetch(64 * c_first + lane);
+    for (int c = c_first; c <= c_last; ++c) {
         const int u = 64 * c + lane;
         float g[NR];
         const float den = (u == 0 || u == L - 1) ? cf.spacing : two_sp;
@@ -177,25 +185,74 @@ __device__ __forceinline__ void stream_rows(const Config& cf, const float* __res
         if (ntaps <= 16) { tap_group(0); tap_group(8); }
         else if (ntaps <= 32) { tap_group(0); tap_group(8); tap_group(16); tap_group(24); }
         else for (int j = 0; j < ntaps; j += 8) tap_group(j);
-        if (MOMENTS) {
-            if (in_row) {
-#pragma unroll
-                for (int r = 0; r < NR; ++r) { mom[0] += (double)sm[r]; mom[1] += (double)sm[r] * (double)sm[r]; }
-            }
-            continue;
-        }
         const unsigned long long V = __ballot(in_row && i < L - 1);       // an edge index is 0 .. L-2
-        const int base_prev = 64 * (c - 1) - rad;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const unsigned long long P = __ballot(in_row && sm[r] > cf.th_pos);     // grad > thres_pos (:23)
             const unsigned long long M = __ballot(in_row && sm[r] < cf.th_neg);     // grad < thres_neg (:24)
-            if (c > 0) {
-                const unsigned long long EP = ~st[r].P & ((st[r].P >> 1) | (P << 63)) & st[r].V;
-                const unsigned long long EM = ~st[r].M & ((st[r].M >> 1) | (M << 63)) & st[r].V;
-                pair_word(st[r], base_prev, EP, EM, lane, cf, out[r], [&](int idx) { return env_at(r, idx); });
+            sink(c, r, P, M, V, in_row ? sm[r] : 0.f);
+        }
+    }
+}
+
+// The whole row in one call, with the pairing (MOMENTS = false) or the sums of the blurred gradient (MOMENTS = true,
+// the Q7 pre-pass) applied on the fly.
+//   env_at(r, i)     : envelope of row r at sample i (amplitude of a kept peak)
+template <int NR, bool MOMENTS, class EnvPair, class EnvAt>
+__device__ __forceinline__ void stream_rows(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring,
+                                            int lane, EnvPair env_pair, EnvAt env_at, float* const (&out)[NR],
+                                            RowState (&st)[NR], double (&mom)[2]) {
+    const int rad = cf.radius;
+    stream_words<NR>(cf, taps, ring, lane, env_pair, 0, word_count(cf.L, rad) - 1, true,
+                     [&](int c, int r, unsigned long long P, unsigned long long M, unsigned long long V, float sm) {
+                         if (MOMENTS) {
+                             mom[0] += (double)sm;                         // lanes outside the row deliver 0
+                             mom[1] += (double)sm * (double)sm;
+                             return;
+                         }
+                         if (c > 0) {                                      // an edge at the last lane needs this word's first flag
+                             const unsigned long long EP = ~st[r].P & ((st[r].P >> 1) | (P << 63)) & st[r].V;
+                             const unsigned long long EM = ~st[r].M & ((st[r].M >> 1) | (M << 63)) & st[r].V;
+                             pair_word(st[r], 64 * (c - 1) - rad, EP, EM, lane, cf, out[r], [&](int idx) { return env_at(r, idx); });
+                         }
+                         st[r].P = P; st[r].M = M; st[r].V = V;
+                     });
+}
+
+// Pairing of a row from its stored flag words F[3 c + {0, 1, 2}] = (P, M, V) of iteration c, c = 0 .. nwords - 1 (LDS, by
+// one wave).  64 iterations at a time: lane l forms the edge words of iteration c0 + l in vector registers, a ballot
+// tells which iterations hold an onset, and the scalar loop visits only those and the stretch behind a pending onset.
+template <class EnvAt>
+__device__ __forceinline__ void pair_stored_words(RowState& st, const unsigned long long* __restrict__ F, int nwords, int lane,
+                                                  const Config& cf, float* __restrict__ out, EnvAt env_at) {
+    const int rad = cf.radius;
+    for (int c0 = 1; c0 < nwords; c0 += 64) {
+        const int c = c0 + lane;
+        unsigned long long EP = 0, EM = 0;
+        if (c < nwords) {
+            const unsigned long long Pp = F[3 * (c - 1)], Mp = F[3 * (c - 1) + 1], Vp = F[3 * (c - 1) + 2];
+            const unsigned long long P = F[3 * c], M = F[3 * c + 1];
+            EP = ~Pp & ((Pp >> 1) | (P << 63)) & Vp;
+            EM = ~Mp & ((Mp >> 1) | (M << 63)) & Vp;
+        }
+        const unsigned long long has_ep = __ballot(EP != 0), has_em = __ballot(EM != 0);
+        st.any_ap |= (has_ep != 0);
+        st.any_am |= (has_em != 0);
+        const unsigned ep_lo = (unsigned)EP, ep_hi = (unsigned)(EP >> 32), em_lo = (unsigned)EM, em_hi = (unsigned)(EM >> 32);
+        int l = 0;
+        while (l < 64) {
+            if (st.last_ap < 0 || st.done) {                  // nothing pending: jump to the next iteration with an onset
+                const unsigned long long rest = l ? (has_ep >> l) << l : has_ep;
+                if (!rest) break;
+                l = __builtin_ctzll(rest);
             }
-            st[r].P = P; st[r].M = M; st[r].V = V;
+            // (the builtin returns int: without the casts a set bit 31 of the low half would sign-extend over the high half)
+            const unsigned long long ep = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ep_hi, l) << 32) |
+                                          (unsigned long long)(unsigned)__builtin_amdgcn_readlane(ep_lo, l);
+            const unsigned long long em = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(em_hi, l) << 32) |
+                                          (unsigned long long)(unsigned)__builtin_amdgcn_readlane(em_lo, l);
+            pair_word(st, 64 * (c0 + l - 1) - rad, ep, em, lane, cf, out, env_at);
+            ++l;
         }
     }
 }

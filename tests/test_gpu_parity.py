@@ -508,6 +508,44 @@ def test_gradpeak_1024_rows_exact_vs_reference(dev, rf, thn, th):
     assert np.array_equal(em3[same], g[f'em3_rf{rf}_th{thn}'][same])
 
 
+@pytest.mark.parametrize('W', [1, 2, 4])
+def test_gradpeak_split_kernel_matches_row_kernel(dev, W, monkeypatch):
+    """gradpeak_split_kernel (rows split over W waves, envelope staged through LDS, stored flag words paired afterwards)
+    against gradpeak_rows_kernel (one wave per row, pairing on the fly) through the C ABI: identical echoes, counts and
+    moments for explicit, zero and device-side thresholds, short rows (fewer words than waves) included.  The library
+    reads STOF_GP_SPLIT on every call: 0 = row kernel, 2 / 3 / 4 = split kernel with 1 / 2 / 4 waves per row."""
+    from stofnet_amd import _lib
+    from stofnet_amd.gradpeak import gaussian_kernel_1d
+    from stofnet_amd.hilbert import hilbert_envelope
+    lib = _lib.lib()
+
+    def run(rows, L, rf, th):
+        x = torch.from_numpy(synth.synth_echo(rows, L, seed=rows + L, noise=0.01)).to(dev)[:, 0].contiguous()
+        env = hilbert_envelope(x)
+        gs = rf // 6 * 5
+        taps = gaussian_kernel_1d((gs * 2 - 1) / 6).to(dev).float()
+        rad = (taps.numel() - 1) // 2
+        stats = torch.tensor([0.0, 0.0, float(rows * L)], dtype=torch.float64, device=dev)
+        _lib.check(lib.stof_gradpeak_moments(_lib.ptr(env), rows, L, gs, _lib.ptr(taps), rad, _lib.ptr(stats), _lib.stream_ptr(dev)), 'moments')
+        cap = 128
+        e = torch.zeros(rows, cap, 3, device=dev)
+        c = torch.zeros(rows, dtype=torch.int32, device=dev)
+        f = torch.zeros(2, dtype=torch.int32, device=dev)
+        _lib.check(lib.stof_grad_peak_detect(_lib.ptr(env), rows, L, gs, _lib.ptr(taps), rad, th, None, rf, 50 * rf, 0, _lib.ptr(e), cap,
+                                             None, _lib.ptr(c), _lib.ptr(f), _lib.stream_ptr(dev)), 'detect')
+        torch.cuda.synchronize()
+        return stats.cpu().numpy(), c.cpu().numpy(), f.cpu().numpy(), e.cpu().numpy()
+
+    for case in ((6, 2000, 10, 1e-3), (6, 2000, 10, 0.0), (5, 4000, 20, 1e-3), (3, 9000, 20, 1e-4), (2, 300, 10, 1e-3), (7, 64, 10, 1e-3)):
+        monkeypatch.setenv('STOF_GP_SPLIT', '0')
+        s0, c0, f0, e0 = run(*case)
+        monkeypatch.setenv('STOF_GP_SPLIT', {1: '2', 2: '3', 4: '4'}[W])
+        s1, c1, f1, e1 = run(*case)
+        assert np.array_equal(c0, c1) and np.array_equal(f0, f1) and np.array_equal(e0, e1), case
+        assert np.allclose(s0, s1, rtol=1e-12, atol=0), case          # double sums in a different order
+        assert c0.sum() > 0 or case[1] < 400
+
+
 @pytest.mark.parametrize('L', [30720, 40000])
 def test_long_rows_hilbert_and_gradpeak_vs_reference(dev, L):
     """Rows beyond LDS (the reference's PALA GradPeak run uses rf_scale_factor 20 on ~30,720-sample frames,

@@ -59,8 +59,9 @@ def case_hilbert(rows, n):
     return (lambda: hilbert_envelope(x)), 2 * x.numel() * 4, 'row read + envelope write'
 
 
-def case_gradpeak(rows, n, rf, th, chirp=False):
-    x = torch.from_numpy(synth.synth_echo(rows, n, seed=3, noise=0.01)).to(dev)
+def case_gradpeak(rows, n, rf, th, chirp=False, long_rows=False):
+    kw = dict(noise=0.0005, attack=300, tau=3000.0, carrier=0.001) if long_rows else dict(noise=0.01)
+    x = torch.from_numpy(synth.synth_echo(rows, n, seed=3, **kw)).to(dev)
     if chirp:
         gp = GradPeak(threshold=th, rescale_factor=rf, echo_max=1, onset_opt=True)
         return (lambda: gp(x)), x.numel() * 4, 'row read (echoes are a few bytes per row); GradPeak module, chirp config, incl. the one host read'
@@ -92,6 +93,7 @@ CASES = {
     'gradpeak_chirp_4096x2000_rf10_th1em3': lambda: case_gradpeak(4096, 2000, 10, 1e-3, chirp=True),
     'gradpeak_default_th_4096x2000_rf10': lambda: case_gradpeak(4096, 2000, 10, None),
     'gradpeak_unfused_4096x4000_rf20_th1em3': lambda: case_gradpeak(4096, 4000, 20, 1e-3),
+    'gradpeak_long_512x30720_rf20_th1em4': lambda: case_gradpeak(512, 30720, 20, 1e-4, long_rows=True),
 }
 
 
