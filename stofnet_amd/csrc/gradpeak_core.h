@@ -60,12 +60,53 @@ struct RowState {
 // falling-slope edge every dozen samples but only a few onsets, so the work is per onset, not per edge: a word without
 // a pending onset and without a new one costs one scalar test.  (The reference's 2**32 sentinel, :43 / Q8, maps a peak
 // without a preceding onset to the first onset; such a peak is dropped here as it is there for any ival_min >= 0.)
+__device__ __forceinline__ int msb64(unsigned long long v) { return 63 - __builtin_clzll(v); }
+
+// The same pairing for a word crowded with onsets (a threshold near zero makes every noise wiggle an onset): one lane
+// per sample, each falling-slope edge looks up its onset with mask arithmetic and a ballot prefix orders the survivors.
+// Same state as the per-onset form: `done` <=> the last surviving candidate's onset is last_ap.
+template <class EnvAt>
+__device__ __forceinline__ void pair_word_dense(RowState& st, int base, unsigned long long EP, unsigned long long EM, int lane,
+                                                const Config& cf, float* __restrict__ out, EnvAt env_at) {
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long le_mask = lt_mask | (1ull << lane);
+    const int i = base + lane;
+    const bool em = (EM >> lane) & 1ull;
+    const unsigned long long below = EP & le_mask;             // nearest preceding (<=) onset of this lane's edge (:42-45)
+    const int ap = below ? (base + msb64(below)) : st.last_ap;
+    const int gap = i - ap;
+    const bool valid = em && (ap >= 0) && (gap > cf.ival_min) && (gap < cf.ival_max);     // :48-49
+    const unsigned long long vm = __ballot(valid);
+    const unsigned long long vbelow = vm & lt_mask;
+    const int prev_ap_lane = __shfl(ap, vbelow ? msb64(vbelow) : 0);
+    const int prev_ap = vbelow ? prev_ap_lane : (st.done ? st.last_ap : -2);   // onset of the previous surviving candidate
+    const bool keep = valid && (ap != prev_ap);                // first am per distinct ap (:58-59)
+    const unsigned long long km = __ballot(keep);
+    if (keep) {
+        const long long pos = st.nout + __builtin_popcountll(km & lt_mask);
+        if (pos < cf.cap) {
+            out[3 * pos + 0] = (float)ap;
+            out[3 * pos + 1] = (float)i;
+            out[3 * pos + 2] = env_at(i);                      // data[i, am] (:66)
+        }
+    }
+    st.nout += __builtin_popcountll(km);
+    const int last_valid_ap = vm ? __shfl(ap, msb64(vm)) : (st.done ? st.last_ap : -2);
+    if (EP) st.last_ap = base + msb64(EP);
+    st.done = (last_valid_ap == st.last_ap);
+}
+
 template <class EnvAt>
 __device__ __forceinline__ void pair_word(RowState& st, int base, unsigned long long EP, unsigned long long EM, int lane,
                                           const Config& cf, float* __restrict__ out, EnvAt env_at) {
     st.any_ap |= (EP != 0);
     st.any_am |= (EM != 0);
     if (EP == 0 && (st.last_ap < 0 || st.done)) return;
+    if (__builtin_popcountll(EP) > 2) {                        // wave-uniform
+        if (EM) pair_word_dense(st, base, EP, EM, lane, cf, out, env_at);
+        else { st.last_ap = base + msb64(EP); st.done = 0; }
+        return;
+    }
     unsigned long long ep = EP;
     int lo = 0;                                              // the pending onset owns bits [lo, next onset)
     while (true) {
