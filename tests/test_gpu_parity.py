@@ -574,6 +574,29 @@ def test_hilbert_beyond_lds_vs_oracle(dev, n):
     assert np.abs(env - po.hilbert_envelope(x)).max() < ENV_TOL
 
 
+@pytest.mark.parametrize('n', [23040, 30000, 65536, 81920])
+def test_hilbert_four_step_factorisations(dev, n):
+    """Rows beyond LDS as n = R0 * M: every outer radix and inner compile-time length the planner can pick beyond the
+    lengths of the other tests (23040 = 15 * 1536, 30000 = 15 * 2000, 65536 = 16 * 4096, 81920 = 20 * 4096), odd batch."""
+    from stofnet_amd import hilbert_transform
+    x = synth.synth_randn(3, n, seed=n)[:, 0]
+    v = hilbert_transform(torch.from_numpy(x).to(dev)).cpu().numpy()
+    want = po.hilbert_transform(x)
+    assert np.abs(v.real - want.real).max() < ENV_TOL and np.abs(v.imag - want.imag).max() < ENV_TOL
+
+
+def test_hilbert_four_step_several_chunks(dev):
+    """The four-step scratch is sized for a chunk of pairs (64 MB); 601 rows of 30,720 samples = 301 pairs = two chunks,
+    the second one short and ending in a lone row."""
+    from stofnet_amd.hilbert import hilbert_envelope
+    rows, n = 601, 30720
+    x = synth.synth_randn(rows, n, seed=9)[:, 0]
+    env = hilbert_envelope(torch.from_numpy(x).to(dev)).cpu().numpy()
+    pick = np.r_[0:4, 270:280, 544:550, 596:601]                 # rows around the chunk boundary (pairs 272 | 273) and the tail
+    assert np.abs(env[pick] - po.hilbert_envelope(x[pick])).max() < ENV_TOL
+    assert np.isfinite(env).all() and np.abs(env).max() < 10
+
+
 def test_gradpeak_many_rows_margin_gated_exactness(dev):
     """4096 rows against the float64 oracle.  A threshold crossing is decided by one comparison of a float that the
     two implementations round differently, so exactness is asserted for every row whose smoothed gradient stays

@@ -55,13 +55,17 @@ def case_pick_sync(m, th):
 
 
 def case_hilbert(rows, n):
-    x = torch.from_numpy(synth.synth_randn(rows, n, seed=1)).to(dev)[:, 0].contiguous()
+    x = torch.from_numpy(synth.synth_randn(min(rows, 4096), n, seed=1)).to(dev)[:, 0].contiguous()
+    if rows > 4096:
+        x = x.repeat(rows // 4096, 1).contiguous()
     return (lambda: hilbert_envelope(x)), 2 * x.numel() * 4, 'row read + envelope write'
 
 
 def case_gradpeak(rows, n, rf, th, chirp=False, long_rows=False):
     kw = dict(noise=0.0005, attack=300, tau=3000.0, carrier=0.001) if long_rows else dict(noise=0.01)
-    x = torch.from_numpy(synth.synth_echo(rows, n, seed=3, **kw)).to(dev)
+    x = torch.from_numpy(synth.synth_echo(min(rows, 4096), n, seed=3, **kw)).to(dev)
+    if rows > 4096:
+        x = x.repeat(rows // 4096, 1, 1).contiguous()
     if chirp:
         gp = GradPeak(threshold=th, rescale_factor=rf, echo_max=1, onset_opt=True)
         return (lambda: gp(x)), x.numel() * 4, 'row read (echoes are a few bytes per row); GradPeak module, chirp config, incl. the one host read'
@@ -83,6 +87,8 @@ CASES = {
     'mask2coords_argmax_m20000': lambda: case_pick_sync(20000, None),
     'hilbert_4096x1536': lambda: case_hilbert(4096, 1536),
     'hilbert_4096x2000': lambda: case_hilbert(4096, 2000),
+    'hilbert_16384x2000': lambda: case_hilbert(16384, 2000),
+    'hilbert_65536x2000': lambda: case_hilbert(65536, 2000),
     'hilbert_4096x2048': lambda: case_hilbert(4096, 2048),
     'hilbert_4096x4000': lambda: case_hilbert(4096, 4000),
     'hilbert_4096x4096': lambda: case_hilbert(4096, 4096),
@@ -90,6 +96,7 @@ CASES = {
     'hilbert_1024x20000': lambda: case_hilbert(1024, 20000),
     'hilbert_512x30720': lambda: case_hilbert(512, 30720),
     'gradpeak_fused_4096x2000_rf10_th1em3': lambda: case_gradpeak(4096, 2000, 10, 1e-3),
+    'gradpeak_fused_32768x2000_rf10_th1em3': lambda: case_gradpeak(32768, 2000, 10, 1e-3),
     'gradpeak_chirp_4096x2000_rf10_th1em3': lambda: case_gradpeak(4096, 2000, 10, 1e-3, chirp=True),
     'gradpeak_default_th_4096x2000_rf10': lambda: case_gradpeak(4096, 2000, 10, None),
     'gradpeak_unfused_4096x4000_rf20_th1em3': lambda: case_gradpeak(4096, 4000, 20, 1e-3),
