@@ -211,37 +211,60 @@ __global__ __launch_bounds__(256) void pick_threshold_kernel(const float* __rest
     int* out = idx + row * idx_cap;
     const bool aligned = ((reinterpret_cast<size_t>(s) & 15) == 0);
     int base = 0;                               // detections emitted so far in this row
+    // A chunk is requested one iteration ahead (16-byte pieces + the two halos in registers) and lands in LDS at the
+    // top of its iteration, so the HBM latency of chunk k+1 hides behind the scan of chunk k.
+    float4 nxt[PK_CH / 1024];
+    float hl = -INFINITY, hr = -INFINITY;
+    auto request = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < PK_CH / 1024; ++q) {
+            const int t = c0 + 4 * (tid + 256 * q);
+            if (aligned && t + 3 < M) nxt[q] = *reinterpret_cast<const float4*>(s + t);
+            else nxt[q] = make_float4(t < M ? s[t] : -INFINITY, t + 1 < M ? s[t + 1] : -INFINITY,
+                                      t + 2 < M ? s[t + 2] : -INFINITY, t + 3 < M ? s[t + 3] : -INFINITY);
+        }
+        if (tid < half) {                                        // max_pool1d pads with -inf
+            const int tl = c0 - half + tid, tr = c0 + PK_CH + tid;
+            hl = (tl >= 0) ? s[tl] : -INFINITY;
+            hr = (tr < M) ? s[tr] : -INFINITY;
+        }
+    };
+    request(0);
     for (int c0 = 0; c0 < M; c0 += PK_CH) {
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < PK_CH / 1024; ++q) {
-            const int i = 4 * (tid + 256 * q);
-            const int t = c0 + i;
-            float4 v;
-            if (aligned && t + 3 < M) v = *reinterpret_cast<const float4*>(s + t);
-            else v = make_float4(t < M ? s[t] : -INFINITY, t + 1 < M ? s[t + 1] : -INFINITY,
-                                 t + 2 < M ? s[t + 2] : -INFINITY, t + 3 < M ? s[t + 3] : -INFINITY);
-            *reinterpret_cast<float4*>(buf + PK_MAXHALF + i) = v;
-        }
-        for (int i = tid; i < half; i += 256) {
-            const int tl = c0 - half + i, tr = c0 + PK_CH + i;
-            buf[PK_MAXHALF - half + i] = (tl >= 0) ? s[tl] : -INFINITY;
-            buf[PK_MAXHALF + PK_CH + i] = (tr < M) ? s[tr] : -INFINITY;
+        for (int q = 0; q < PK_CH / 1024; ++q) *reinterpret_cast<float4*>(buf + PK_MAXHALF + 4 * (tid + 256 * q)) = nxt[q];
+        if (tid < half) {
+            buf[PK_MAXHALF - half + tid] = hl;
+            buf[PK_MAXHALF + PK_CH + tid] = hr;
         }
         __syncthreads();
-        // thread owns PK_PER consecutive samples c0 + PK_PER*tid + e (thread order = time order);
-        // only samples that already pass the threshold (sparse) pay for the window maximum
-        unsigned hitmask = 0;
+        if (c0 + PK_CH < M) request(c0 + PK_CH);
+        // thread owns PK_PER consecutive samples c0 + PK_PER*tid + e (thread order = time order).  Candidates (>= threshold,
+        // non-zero: `thresholding` zeroes the rest and `nonzero` drops zeros) are found branch-free from four 16-byte LDS
+        // reads -- the sample-by-sample loop with its compares and branches was 24 VALU instructions per sample, the
+        // kernel's actual bound -- and only they pay for the window maximum.  Samples beyond the row are -inf in `buf`.
+        unsigned cand = 0;
+        {
+            const float4* own = reinterpret_cast<const float4*>(buf + PK_MAXHALF + PK_PER * tid);
 #pragma unroll
-        for (int e = 0; e < PK_PER; ++e) {
-            const int bi = PK_MAXHALF + PK_PER * tid + e;
-            const int t = c0 + PK_PER * tid + e;
-            const float v = buf[bi];
-            if (t < M && v >= threshold && v != 0.f) {
-                float wm = v;
-                for (int d = 1; d <= half; ++d) wm = fmaxf(wm, fmaxf(buf[bi - d], buf[bi + d]));
-                if (v == wm) hitmask |= 1u << e;
+            for (int q = 0; q < PK_PER / 4; ++q) {
+                const float4 v = own[q];
+                cand |= (unsigned)(v.x >= threshold && v.x != 0.f) << (4 * q);
+                cand |= (unsigned)(v.y >= threshold && v.y != 0.f) << (4 * q + 1);
+                cand |= (unsigned)(v.z >= threshold && v.z != 0.f) << (4 * q + 2);
+                cand |= (unsigned)(v.w >= threshold && v.w != 0.f) << (4 * q + 3);
             }
+        }
+        unsigned hitmask = 0;
+        while (cand) {
+            const int e = __builtin_ctz(cand);
+            cand &= cand - 1;
+            const int bi = PK_MAXHALF + PK_PER * tid + e;
+            const float v = buf[bi];
+            float wm = v;
+            for (int d = 1; d <= half; ++d) wm = fmaxf(wm, fmaxf(buf[bi - d], buf[bi + d]));
+            if (v == wm) hitmask |= 1u << e;
         }
         const int nh = __builtin_popcount(hitmask);
         int incl = nh;
