@@ -27,18 +27,21 @@ namespace {
 using stof_gp::Config;
 using stof_gp::RowState;
 constexpr int LDS_BYTES = 160 * 1024;
-constexpr int ROWS_WAVES = 4;            // waves (= rows in flight) per work-group of gradpeak_rows_kernel
+// waves (= rows in flight) per work-group of gradpeak_rows_kernel: 4 when detecting; 16 for the moments, whose work-groups
+// end in two double-precision atomic adds on ONE pair of addresses (~90 atomics per microsecond: 1024 small groups spent
+// 20 us of a 40 us kernel queueing there; 256 groups of 16 waves do not)
+constexpr int ROWS_WAVES = 4, MOMENT_WAVES = 16;
 
-template <bool MOMENTS>
-__global__ __launch_bounds__(64 * ROWS_WAVES) void gradpeak_rows_kernel(const float* __restrict__ env, long long N, Config cf,
+template <bool MOMENTS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gradpeak_rows_kernel(const float* __restrict__ env, long long N, Config cf,
                                                                         const float* __restrict__ taps,
                                                                         const float* __restrict__ th_dev,
                                                                         float* __restrict__ echoes, float* __restrict__ reduced,
                                                                         int* __restrict__ counts, int* __restrict__ flags,
                                                                         double* __restrict__ stats) {
     __shared__ __attribute__((aligned(16))) float tp[stof_gp::TAPS_LDS];
-    __shared__ float rings[ROWS_WAVES][512];
-    __shared__ double red[2][ROWS_WAVES];
+    __shared__ float rings[WAVES][512];
+    __shared__ double red[2][WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     stof_gp::stage_taps(tp, taps, cf.radius, tid, blockDim.x);
     if (th_dev != nullptr) {                                   // default threshold computed on the device (Q7)
@@ -47,13 +50,27 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void gradpeak_rows_kernel(const fl
     }
     __syncthreads();
     double mom[2] = {0.0, 0.0};
-    for (long long row = (long long)blockIdx.x * ROWS_WAVES + wave; row < N; row += (long long)gridDim.x * ROWS_WAVES) {
+    int kmax = 0;                                              // largest echo count among this wave's rows
+    for (long long row = (long long)blockIdx.x * WAVES + wave; row < N; row += (long long)gridDim.x * WAVES) {
         const float* e = env + row * (long long)cf.L;
         float* const out[1] = {MOMENTS ? nullptr : echoes + row * cf.cap * 3};
         RowState st[1];
         stof_gp::stream_rows<1, MOMENTS>(
             cf, tp, rings[wave], lane, [&](int u, float (&v)[1]) { v[0] = e[u]; }, [&](int, int i) { return e[i]; }, out, st, mom);
-        if constexpr (!MOMENTS) stof_gp::finish_row(st[0], cf, row, out[0], reduced, counts, flags, lane);
+        if constexpr (!MOMENTS) {
+            stof_gp::finish_row(st[0], cf, row, out[0], reduced, counts, flags, lane, true);
+            kmax = st[0].nout > kmax ? st[0].nout : kmax;
+        }
+    }
+    if (!MOMENTS) {                                            // Kmax of the batch: one atomic per work-group, not per row
+        int* const wmax = reinterpret_cast<int*>(&red[0][0]);
+        if (lane == 0) wmax[wave] = kmax;
+        __syncthreads();
+        if (tid == 0) {
+            int m = 0;
+            for (int w = 0; w < WAVES; ++w) m = wmax[w] > m ? wmax[w] : m;
+            if (m > 0 && m > __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[1], m);
+        }
     }
     if (MOMENTS) {
 #pragma unroll
@@ -65,7 +82,7 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void gradpeak_rows_kernel(const fl
         __syncthreads();
         if (tid == 0) {
             double a = 0.0, b = 0.0;
-            for (int w = 0; w < ROWS_WAVES; ++w) { a += red[0][w]; b += red[1][w]; }
+            for (int w = 0; w < WAVES; ++w) { a += red[0][w]; b += red[1][w]; }
             atomicAdd(&stats[0], a);
             atomicAdd(&stats[1], b);
         }
@@ -361,10 +378,10 @@ extern "C" int stof_gradpeak_moments(const float* env, int64_t N, int64_t L, int
         if (launch_split<true>(env, N, cf, taps, nullptr, nullptr, nullptr, nullptr, nullptr, stats, static_cast<hipStream_t>(stream), &st))
             return st;
     }
-    int64_t grid = (N + ROWS_WAVES - 1) / ROWS_WAVES;
-    const int64_t maxg = (int64_t)stof::device_cu_count() * 8;
+    int64_t grid = (N + MOMENT_WAVES - 1) / MOMENT_WAVES;
+    const int64_t maxg = (int64_t)stof::device_cu_count() * 2;
     if (grid > maxg) grid = maxg;
-    hipLaunchKernelGGL(gradpeak_rows_kernel<true>, dim3((unsigned)grid), dim3(64 * ROWS_WAVES), 0,
+    hipLaunchKernelGGL((gradpeak_rows_kernel<true, MOMENT_WAVES>), dim3((unsigned)grid), dim3(64 * MOMENT_WAVES), 0,
                        static_cast<hipStream_t>(stream), env, (long long)N, cf, taps, nullptr, nullptr, nullptr, nullptr, nullptr,
                        stats);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
@@ -395,7 +412,7 @@ extern "C" int stof_grad_peak_detect(const float* env, int64_t N, int64_t L, int
     int64_t grid = (N + ROWS_WAVES - 1) / ROWS_WAVES;
     const int64_t maxg = (int64_t)stof::device_cu_count() * 8;
     if (grid > maxg) grid = maxg;
-    hipLaunchKernelGGL(gradpeak_rows_kernel<false>, dim3((unsigned)grid), dim3(64 * ROWS_WAVES), 0,
+    hipLaunchKernelGGL((gradpeak_rows_kernel<false, ROWS_WAVES>), dim3((unsigned)grid), dim3(64 * ROWS_WAVES), 0,
                        static_cast<hipStream_t>(stream), env, (long long)N, cf, taps, threshold_dev, echoes, reduced, counts, flags,
                        nullptr);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;

@@ -351,9 +351,10 @@ __device__ __attribute__((noinline)) void reduce_row(const float* src, long long
 }
 
 // end of a row: counts, batch flags (Q9, Kmax) and the optional reduction
+// defer_kmax: the caller folds st.nout into flags[1] itself (one atomic per work-group at the end of the kernel)
 __device__ __forceinline__ void finish_row(const RowState& st, const Config& cf, long long row, float* __restrict__ out,
                                            float* __restrict__ reduced, int* __restrict__ counts, int* __restrict__ flags,
-                                           int lane) {
+                                           int lane, bool defer_kmax = false) {
     // zero padding of the row up to `cap` (the reference pads with [0, 0, 0], :66)
     for (long long q = 3ll * (st.nout < cf.cap ? st.nout : cf.cap) + lane; q < 3 * cf.cap; q += 64) out[q] = 0.f;
     if (lane == 0) {
@@ -361,7 +362,7 @@ __device__ __forceinline__ void finish_row(const RowState& st, const Config& cf,
         if (st.any_ap && st.any_am && st.nout == 0) atomicOr(&flags[0], 1);       // Q9 (:54-55)
         // Kmax of the batch.  One atomic per row on ONE word serialises at ~90 per microsecond (4096 rows = the whole
         // kernel); the word only grows, so a relaxed read first lets all but the first few record-setting rows skip it.
-        if (st.nout > 0 && st.nout > __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        if (!defer_kmax && st.nout > 0 && st.nout > __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(&flags[1], st.nout);
     }
     if (reduced != nullptr && cf.echo_max > 0) {
