@@ -91,7 +91,9 @@ __device__ __forceinline__ void pair_word_dense(RowState& st, int base, unsigned
         }
     }
     st.nout += __builtin_popcountll(km);
-    const int last_valid_ap = vm ? __shfl(ap, msb64(vm)) : (st.done ? st.last_ap : -2);
+    // (readlane, not a shuffle: the result must stay wave-uniform for the compiler, or the whole pairing state turns into
+    // vector registers and every test on it into an exec-masked region)
+    const int last_valid_ap = vm ? __builtin_amdgcn_readlane(ap, msb64(vm)) : (st.done ? st.last_ap : -2);
     if (EP) st.last_ap = base + msb64(EP);
     st.done = (last_valid_ap == st.last_ap);
 }
