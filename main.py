@@ -25,7 +25,7 @@ import torch
 script_path = Path(__file__).parent.resolve()
 sys.path.insert(0, str(script_path))
 
-from stofnet_amd import GradPeak, StofNet, mask2coords          # noqa: E402
+from stofnet_amd import EDSR_1D, ESPCN_1D, GradPeak, StofNet, mask2coords          # noqa: E402
 from stofnet_amd import config as config_mod                     # noqa: E402
 from stofnet_amd.metrics import toa_rmse                         # noqa: E402
 
@@ -94,6 +94,12 @@ def main(argv=None):
     name = str(cfg.model).lower()
     if name == 'stofnet':
         model = StofNet(upsample_factor=cfg.upsample_factor, precision=cfg.precision)
+    elif name == 'edsr':                                                  # main.py:139-142: baselines riding on SampleShuffle1D
+        model = EDSR_1D(num_channels=1, num_features=64, num_blocks=8, upscale_factor=cfg.upsample_factor)
+        cfg.evaluate = True
+    elif name == 'espcn':
+        model = ESPCN_1D(upscale_factor=cfg.upsample_factor)
+        cfg.evaluate = True
     elif name == 'gradpeak':
         chirp = 'chirp' in str(cfg.data_dir).lower()
         model = GradPeak(threshold=cfg.th, rescale_factor=cfg.rf_scale_factor,
@@ -201,7 +207,7 @@ def evaluate(model, name, frames, gt, cfg, log=None):
             torch.cuda.synchronize()
             tic = time.perf_counter()
             out = model(frame)
-            if name == 'stofnet':
+            if name in ('stofnet', 'edsr', 'espcn'):                     # main.py:318-320
                 es = mask2coords(out, window_size=cfg.nms_win_size, threshold=cfg.th,
                                  upsample_factor=cfg.upsample_factor)
             else:

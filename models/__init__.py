@@ -1,7 +1,8 @@
 """Drop-in for the reference's `models` package (models/__init__.py): `from models import StofNet, ..., GradPeak`
-(main.py:18) resolves unchanged.  StofNet and GradPeak run on the gfx950 kernels (stofnet_amd); the comparison
-networks of the paper's table are outside the accelerated path and raise when constructed."""
-from stofnet_amd import GradPeak, StofNet  # noqa: F401
+(main.py:18) resolves unchanged.  StofNet and GradPeak run on the gfx950 kernels (stofnet_amd); EDSR_1D and
+ESPCN_1D ride on the SampleShuffle1D kernel (their convolutions stay stock ATen, as in the reference); the other
+comparison networks of the paper's table are outside the accelerated path and raise when constructed."""
+from stofnet_amd import EDSR_1D, ESPCN_1D, GradPeak, StofNet  # noqa: F401
 from stofnet_amd.stofnet import SemiGlobalBlock  # noqa: F401
 
 
@@ -18,6 +19,4 @@ ZonziniNetLarge = _out_of_scope('ZonziniNetLarge')
 ZonziniNetSmall = _out_of_scope('ZonziniNetSmall')
 SincNet = _out_of_scope('SincNet')
 Kuleshov = _out_of_scope('Kuleshov')
-EDSR_1D = _out_of_scope('EDSR_1D')
-ESPCN_1D = _out_of_scope('ESPCN_1D')
 WaveUnet = _out_of_scope('WaveUnet')

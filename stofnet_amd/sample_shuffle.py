@@ -20,10 +20,29 @@ def sample_shuffle(x: torch.Tensor, upsample_factor: int) -> torch.Tensor:
     return out.to(x.dtype)
 
 
+class _ShuffleFn(torch.autograd.Function):
+    """Forward on the kernel; the backward of a permutation is its inverse: out[n, c, w r + k] = in[n, k C + c, w]
+    => d in[n, k C + c, w] = d out[n, c, w r + k] (a view / permute of the incoming gradient, off the hot path)."""
+
+    @staticmethod
+    def forward(ctx, x, r):
+        ctx.r = r
+        return sample_shuffle(x, r)
+
+    @staticmethod
+    def backward(ctx, g):
+        r = ctx.r
+        n, c, m = g.shape
+        w = m // r
+        return g.reshape(n, c, w, r).permute(0, 3, 1, 2).reshape(n, r * c, w).contiguous(), None
+
+
 class SampleShuffle1D(nn.Module):
     def __init__(self, upsample_factor):
         super().__init__()
         self.upsample_factor = upsample_factor
 
     def forward(self, x):
+        if x.requires_grad and torch.is_grad_enabled():
+            return _ShuffleFn.apply(x, self.upsample_factor)
         return sample_shuffle(x, self.upsample_factor)

@@ -25,7 +25,35 @@ def test_reference_import_lines_resolve():
     assert len(m.state_dict()) == 30 and sum(p.numel() for p in m.parameters()) == 645764
     assert len(StofNet(4, semi_global_scale=1).state_dict()) == 26
     with pytest.raises(NotImplementedError, match='out of scope'):
-        EDSR_1D(num_channels=1, num_features=64, num_blocks=8, upscale_factor=4)
+        WaveUnet()
+    # the two baselines that ride on SampleShuffle1D are built (main.py:139-142 constructor calls)
+    e = EDSR_1D(num_channels=1, num_features=64, num_blocks=8, upscale_factor=4)
+    assert len(e.state_dict()) == 38 and e.conv_output.weight.shape == (1, 16, 3)
+    assert ESPCN_1D(upscale_factor=4).conv3.weight.shape == (4, 32, 3)
+
+
+def test_shuffle_riders_have_the_reference_parameter_names():
+    """State-dict names and shapes of EDSR_1D / ESPCN_1D equal those of the reference's modules (fixture
+    tests/golden/f11_shuffle_riders.npz holds the reference's parameters by name), so its checkpoints load strictly."""
+    import os
+    import torch
+    from conftest import ROOT
+    from models import EDSR_1D, ESPCN_1D
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'f11_shuffle_riders.npz'))
+    cases = {'edsr_r4': EDSR_1D(num_channels=1, num_features=16, num_blocks=2, upscale_factor=4),
+             'edsr_r2': EDSR_1D(num_channels=1, num_features=8, num_blocks=1, upscale_factor=2),
+             'espcn_r4': ESPCN_1D(upscale_factor=4), 'espcn_r10': ESPCN_1D(upscale_factor=10)}
+    for tag, model in cases.items():
+        ref = {k.split('__p__')[1]: g[k] for k in g.files if k.startswith(tag + '__p__')}
+        sd = model.state_dict()
+        assert sorted(sd) == sorted(ref), tag
+        assert all(tuple(sd[k].shape) == ref[k].shape for k in sd), tag
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()}, strict=True)
+    # ESPCN's initialisation (models/espcn_1d.py:18-29): zero biases, std 0.001 for the layer fed by 32 channels
+    torch.manual_seed(0)
+    m = ESPCN_1D(upscale_factor=4)
+    assert float(m.conv1.bias.abs().max()) == 0.0 and 5e-4 < float(m.conv3.weight.std()) < 2e-3
+    assert abs(float(m.conv2.weight.std()) - (2.0 / (32 * 3)) ** 0.5) < 0.02
 
 
 def test_config_keeps_the_reference_keys():

@@ -630,6 +630,40 @@ def test_gradpeak_odd_batch_and_single_row(dev):
         assert (full[i, :k, 2] - one[0, :, 2]).abs().max() < ENV_TOL       # a lone row rides its own transform: other rounding
 
 
+# ---------------------------------------------------------------- baselines riding on the shuffle
+@pytest.mark.parametrize('tag', ['edsr_r4', 'edsr_r2', 'espcn_r4', 'espcn_r10'])
+def test_shuffle_riders_match_reference(dev, tag):
+    """EDSR_1D / ESPCN_1D with the reference's own parameters and input (tests/golden/make_golden_r2b.py): stock ATen
+    convolutions + the gfx950 SampleShuffle1D kernel reproduce the reference's output."""
+    from stofnet_amd import EDSR_1D, ESPCN_1D
+    g = golden('f11_shuffle_riders')
+    model = {'edsr_r4': lambda: EDSR_1D(1, 16, 2, 4), 'edsr_r2': lambda: EDSR_1D(1, 8, 1, 2),
+             'espcn_r4': lambda: ESPCN_1D(4), 'espcn_r10': lambda: ESPCN_1D(10)}[tag]()
+    model.load_state_dict({k.split('__p__')[1]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + '__p__')}, strict=True)
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        y = model(torch.from_numpy(g[f'{tag}__x']).to(dev)).cpu().numpy()
+    want = g[f'{tag}__y']
+    assert y.shape == want.shape
+    assert np.abs(y - want).max() < 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_sample_shuffle_backward_is_the_inverse_permutation(dev):
+    """Training the riders needs d(shuffle): compare autograd through the kernel module with autograd through the
+    reference's view / permute formulation (utils/sample_shuffle.py:24-27)."""
+    from stofnet_amd import SampleShuffle1D
+    torch.manual_seed(3)
+    n, r, c, w = 3, 4, 5, 37
+    x = torch.randn(n, r * c, w, device=dev, requires_grad=True)
+    wgt = torch.randn(n, c, w * r, device=dev)
+    y = SampleShuffle1D(r)(x)
+    (y * wgt).sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = x2.view(n, r, c, w).permute(0, 2, 3, 1).contiguous().view(n, c, w * r)
+    (y2 * wgt).sum().backward()
+    assert torch.equal(y, y2) and torch.equal(x.grad, x2.grad)
+
+
 # ---------------------------------------------------------------- neighbours of the path (SURVEY 8f)
 def test_toa_rmse_device(dev):
     from stofnet_amd.metrics import toa_rmse
