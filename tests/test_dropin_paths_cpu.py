@@ -52,8 +52,8 @@ def test_shuffle_riders_have_the_reference_parameter_names():
     # ESPCN's initialisation (models/espcn_1d.py:18-29): zero biases, std 0.001 for the layer fed by 32 channels
     torch.manual_seed(0)
     m = ESPCN_1D(upscale_factor=4)
-    assert float(m.conv1.bias.abs().max()) == 0.0 and 5e-4 < float(m.conv3.weight.std()) < 2e-3
-    assert abs(float(m.conv2.weight.std()) - (2.0 / (32 * 3)) ** 0.5) < 0.02
+    assert float(m.conv1.bias.detach().abs().max()) == 0.0 and 5e-4 < float(m.conv3.weight.detach().std()) < 2e-3
+    assert abs(float(m.conv2.weight.detach().std()) - (2.0 / (32 * 3)) ** 0.5) < 0.02
 
 
 def test_config_keeps_the_reference_keys():
