@@ -445,6 +445,7 @@ int try_launch_ct(const float* x, int64_t nrows, int64_t n, float* env, float* r
         case 2048: return launch_ct<2048, 1, 4>(x, nrows, env, re, im, ncu, stream);
         case 4000: return launch_ct<4000, 2, 2>(x, nrows, env, re, im, ncu, stream);
         case 4096: return launch_ct<4096, 2, 2>(x, nrows, env, re, im, ncu, stream);
+        case 8000: return launch_ct<8000, 4, 2>(x, nrows, env, re, im, ncu, stream);
         default: return -1;
     }
 }

@@ -102,6 +102,7 @@ extern "C" int fft_analytic_ct(int n, float* z, int nthreads) {
         case 2048: return run_ct<2048>(z, nthreads);
         case 4000: return run_ct<4000>(z, nthreads);
         case 4096: return run_ct<4096>(z, nthreads);
+        case 8000: return run_ct<8000>(z, nthreads);
     }
     return 0;
 }

@@ -77,7 +77,7 @@ def test_analytic_signal_matches_oracle(harness, n, nthreads):
     assert np.abs(np.hypot(z.imag, v2) - np.abs(a2)).max() < 1e-5
 
 
-@pytest.mark.parametrize('n', [96, 1536, 2000, 2048, 4000, 4096])
+@pytest.mark.parametrize('n', [96, 1536, 2000, 2048, 4000, 4096, 8000])
 @pytest.mark.parametrize('nthreads', [64, 128, 256])
 def test_compile_time_plans_match_oracle(harness, n, nthreads):
     """analytic_ct<N, T>: constant strides / trip counts, full compile-time twiddle table (the kernels' fast path)."""
