@@ -463,6 +463,26 @@ constexpr int ct_padded(int i) { return i + 2 * (i >> 4); }            // elemen
 constexpr int ct_slot_entries(int n) { return ct_padded(n); }          // complex values per row slot (n % 16 == 0)
 STOF_HD unsigned pad(unsigned i) { return i + 2u * (i >> 4); }
 
+// Options of a compile-time plan.  PAD: the padded layout above (default).  Rows whose padded image would not fit LDS
+// (20,000 values = 160,000 bytes) run unpadded: only the middle pass pays bank conflicts then.  TW2: the twiddle table
+// is the two-level pair of fft_small's run-time plans, w_N^t = TB[t >> 6] * TA[t & 63] (TA at W[0..63], TB behind it),
+// when the full table of N / min-radix entries does not fit next to the image either.
+template <bool PAD_ = true, bool TW2_ = false>
+struct CtOpt {
+    static constexpr bool PAD = PAD_, TW2 = TW2_;
+};
+template <int N> constexpr int ct_tw2_entries() { return TW_A + (ct_plan_for(N).table + TW_A - 1) / TW_A; }
+template <int N>
+constexpr TwTable<ct_tw2_entries<N>()> make_tw_table2() {      // TA[t] = w_N^t (t < 64), then TB[u] = w_N^{64 u}
+    TwTable<ct_tw2_entries<N>()> t{};
+    for (int k = 0; k < ct_tw2_entries<N>(); ++k) {
+        const cd r = ct_root(k < TW_A ? k : (k - TW_A) * TW_A, N);
+        t.w[k].x = (float)r.c;
+        t.w[k].y = (float)r.s;
+    }
+    return t;
+}
+
 template <int R, int UU>
 struct CtGroup {
     cf x[UU][R];
@@ -499,10 +519,10 @@ STOF_HD void ct_pipeline(Load load, Finish finish) {
 }
 
 // One pass of radix R over blocks of M values (M / R a multiple of 16) by T threads; W[t] = w_N^t.
-template <int N, int M, int R, bool INV, int T>
+template <int N, int M, int R, bool INV, int T, class OPT = CtOpt<>>
 STOF_HD void ct_pass(cf* __restrict__ Z, const cf* __restrict__ W, int tid) {
     constexpr int SUB = M / R, TSTEP = N / M, NB = N / R, ITERS = (NB + T - 1) / T;
-    constexpr int SUBP = ct_padded(SUB), MP = ct_padded(M);
+    constexpr int SUBP = OPT::PAD ? ct_padded(SUB) : SUB, MP = OPT::PAD ? ct_padded(M) : M;
     constexpr int U = R >= 8 ? 1 : 2;
     constexpr bool RAGGED = (NB % T) != 0;
     static_assert(SUB % 16 == 0 && N % M == 0 && M % R == 0, "bad pass geometry");
@@ -516,10 +536,12 @@ STOF_HD void ct_pass(cf* __restrict__ Z, const cf* __restrict__ W, int tid) {
             const unsigned bb = G.on[u] ? b : 0u;
             const unsigned blk = (M == N) ? 0u : bb / (unsigned)SUB;
             const unsigned j = (M == N) ? bb : bb - blk * (unsigned)SUB;
-            G.off[u] = blk * (unsigned)MP + pad(j);
+            G.off[u] = blk * (unsigned)MP + (OPT::PAD ? pad(j) : j);
 #pragma unroll
             for (int k = 0; k < R; ++k) G.x[u][k] = Z[G.off[u] + k * SUBP];
-            G.w1[u] = W[j * (unsigned)TSTEP];                                  // w_M^j = w_N^{j TSTEP}
+            const unsigned t = j * (unsigned)TSTEP;                            // w_M^j = w_N^{j TSTEP}
+            if constexpr (OPT::TW2) G.w1[u] = cmul(W[TW_A + (t >> TW_SHIFT)], W[t & (TW_A - 1)]);
+            else G.w1[u] = W[t];
         }
     };
     auto finish = [&](auto& G) {
@@ -560,7 +582,7 @@ template <int N> STOF_HD CtFilter ct_filter_default() {
     CtFilter f; f.one = (float)(1.0 / (double)N); f.two = (float)(2.0 / (double)N); f.edge = true; return f;
 }
 
-template <int N, int T>
+template <int N, int T, class OPT = CtOpt<>>
 STOF_HD void ct_middle16(cf* __restrict__ Z, int tid, const CtFilter filt) {
     constexpr int NB = N / 16, ITERS = (NB + T - 1) / T;
     constexpr bool RAGGED = (NB % T) != 0;
@@ -569,7 +591,7 @@ STOF_HD void ct_middle16(cf* __restrict__ Z, int tid, const CtFilter filt) {
         constexpr int g = decltype(gc)::value;
         const unsigned b = (unsigned)(tid + g * T);
         G.on[0] = !(RAGGED && g == ITERS - 1) || (int)b < NB;
-        G.off[0] = (G.on[0] ? b : 0u) * 18u;
+        G.off[0] = (G.on[0] ? b : 0u) * (OPT::PAD ? 18u : 16u);
 #pragma unroll
         for (int k = 0; k < 16; ++k) G.x[0][k] = Z[G.off[0] + k];
     };
@@ -592,32 +614,32 @@ STOF_HD void ct_middle16(cf* __restrict__ Z, int tid, const CtFilter filt) {
 }
 
 // forward passes on the way down, the middle pass at the bottom, the inverse passes (reverse order) on the way up
-template <int N, int T, int S, int M, class Sync>
+template <int N, int T, int S, int M, class OPT, class Sync>
 STOF_HD void ct_level(cf* __restrict__ Z, const cf* __restrict__ W, int tid, Sync& sync, const CtFilter& filt) {
     constexpr CtPlan P = ct_plan_for(N);
     static_assert(P.npass >= 0, "no compile-time plan for this length");
     if constexpr (S < P.npass) {
         constexpr int R = P.radix[S];
-        ct_pass<N, M, R, false, T>(Z, W, tid);
+        ct_pass<N, M, R, false, T, OPT>(Z, W, tid);
         sync();
-        ct_level<N, T, S + 1, M / R>(Z, W, tid, sync, filt);
-        ct_pass<N, M, R, true, T>(Z, W, tid);
+        ct_level<N, T, S + 1, M / R, OPT>(Z, W, tid, sync, filt);
+        ct_pass<N, M, R, true, T, OPT>(Z, W, tid);
         sync();
     } else {
         static_assert(M == 16, "the middle pass takes the last 16 values");
-        ct_middle16<N, T>(Z, tid, filt);
+        ct_middle16<N, T, OPT>(Z, tid, filt);
         sync();
     }
 }
 
 // analytic signal of the N complex values in the padded slot Z, in place, by T threads (tid < T)
-template <int N, int T, class Sync>
+template <int N, int T, class OPT = CtOpt<>, class Sync>
 STOF_HD void analytic_ct(cf* __restrict__ Z, const cf* __restrict__ W, int tid, Sync sync, const CtFilter filt) {
-    ct_level<N, T, 0, N>(Z, W, tid, sync, filt);
+    ct_level<N, T, 0, N, OPT>(Z, W, tid, sync, filt);
 }
-template <int N, int T, class Sync>
+template <int N, int T, class OPT = CtOpt<>, class Sync>
 STOF_HD void analytic_ct(cf* __restrict__ Z, const cf* __restrict__ W, int tid, Sync sync) {
-    analytic_ct<N, T>(Z, W, tid, sync, ct_filter_default<N>());
+    analytic_ct<N, T, OPT>(Z, W, tid, sync, ct_filter_default<N>());
 }
 
 }  // namespace stof_fft

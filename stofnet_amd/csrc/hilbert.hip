@@ -355,14 +355,16 @@ __global__ __launch_bounds__(512) void hilbert_pairs_kernel(const float* __restr
 // ----------------------------------------------------------------------------------------------------------------
 using stof_ct::CtTwiddles;
 
-template <int N, int WPP, int PPW>
+// PAD / TW2: fft_small.h's CtOpt (rows whose padded image or full twiddle table would not fit LDS go without)
+// KEEP: the pair's rows stay in registers from the load to the un-mixing (otherwise they are read a second time)
+template <int N, int WPP, int PPW, bool PAD = true, bool TW2 = false, bool KEEP = true>
 __global__ __launch_bounds__(64 * WPP * PPW) void hilbert_ct_kernel(const float* __restrict__ x, long long nrows,
                                                                      float* __restrict__ env, float* __restrict__ re,
                                                                      float* __restrict__ im) {
     using namespace stof_fft;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     constexpr int T = 64 * WPP, TT = T * PPW, IO = (N / 4 + T - 1) / T;
-    constexpr int TWP = stof_ct::twiddle_lds_entries<N>(), SLOT = ct_slot_entries(N);
+    constexpr int TWP = TW2 ? stof_ct::twiddle2_lds_entries<N>() : stof_ct::twiddle_lds_entries<N>(), SLOT = PAD ? ct_slot_entries(N) : N;
     cf* const W = reinterpret_cast<cf*>(lds);
     const int slot = threadIdx.x / T, tid = threadIdx.x % T;
     cf* const Z = W + TWP + slot * SLOT;
@@ -370,64 +372,72 @@ __global__ __launch_bounds__(64 * WPP * PPW) void hilbert_ct_kernel(const float*
     long long pr = (long long)blockIdx.x * PPW + slot;
 
     // rows of the first pair on their way while the twiddle table is copied
-    stof_io::PairRegs<IO> cur;
-    auto fetch = [&](stof_io::PairRegs<IO>& r, long long p) {
-        if (p < npairs) {
+    static_assert(KEEP || !PAD, "the direct HBM -> LDS staging writes the unpadded image");
+    stof_io::PairRegs<KEEP ? IO : 1> cur;
+    auto fetch = [&](stof_io::PairRegs<KEEP ? IO : 1>& r, long long p) {
+        if (KEEP && p < npairs) {
             const float* xr = x + 2 * p * (size_t)N;
             stof_io::load_pair_regs(r, xr, 2 * p + 1 < nrows ? xr + N : nullptr, N, tid, T);
         }
     };
     fetch(cur, pr);
-    stof_ct::stage_twiddles<N>(lds, threadIdx.x, TT);
+    if constexpr (TW2) stof_ct::stage_twiddles2<N>(lds, threadIdx.x, TT);
+    else stof_ct::stage_twiddles<N>(lds, threadIdx.x, TT);
     __syncthreads();
     for (long long p0 = (long long)blockIdx.x * PPW; p0 < npairs; p0 += stride, pr += stride) {
         const bool active = pr < npairs;
         if (WPP == 1 && !active) break;                          // a lone wave: nobody waits for it
         auto sync = [] { if (WPP > 1) __syncthreads(); else wave_lds_sync(); };
         sync();                                                   // previous pair fully read back
-        if (active) stof_io::stage_pair<IO, true>(Z, cur, N, tid, T);
+        const float* const xrow = x + 2 * pr * (size_t)N;
+        const float* const xrow2 = 2 * pr + 1 < nrows ? xrow + N : nullptr;
+        if (active) {
+            if constexpr (KEEP) stof_io::stage_pair<IO, PAD>(Z, cur, N, tid, T);
+            else stof_io::load_pair<4>(Z, xrow, xrow2, N, tid, T);
+        }
         sync();
-        analytic_ct<N, T>(Z, W, tid, sync);                       // idle slots of a multi-wave group keep the barrier count
+        analytic_ct<N, T, CtOpt<PAD, TW2>>(Z, W, tid, sync);      // idle slots of a multi-wave group keep the barrier count
         if (!active) continue;
         const long long row = 2 * pr;
         const bool second = row + 1 < nrows;
         float* const e1 = env ? env + row * (size_t)N : nullptr;
         float* const r1 = re ? re + row * (size_t)N : nullptr;
         float* const i1 = im ? im + row * (size_t)N : nullptr;
-        stof_io::unmix_pair_regs<IO, true>(
-            Z, cur, N, tid, T,
-            [&](int q, const float (&xa)[4], const float (&v1)[4], const float (&xb)[4], const float (&v2)[4]) {
-                using stof_io::envelope;
-                if (e1) {
-                    *reinterpret_cast<float4*>(e1 + 4 * q) = make_float4(envelope(xa[0], v1[0]), envelope(xa[1], v1[1]),
-                                                                         envelope(xa[2], v1[2]), envelope(xa[3], v1[3]));
-                    if (second)
-                        *reinterpret_cast<float4*>(e1 + N + 4 * q) = make_float4(envelope(xb[0], v2[0]), envelope(xb[1], v2[1]),
-                                                                                 envelope(xb[2], v2[2]), envelope(xb[3], v2[3]));
-                }
-                if (r1) {
-                    *reinterpret_cast<float4*>(r1 + 4 * q) = make_float4(xa[0], xa[1], xa[2], xa[3]);
-                    if (second) *reinterpret_cast<float4*>(r1 + N + 4 * q) = make_float4(xb[0], xb[1], xb[2], xb[3]);
-                }
-                if (i1) {
-                    *reinterpret_cast<float4*>(i1 + 4 * q) = make_float4(v1[0], v1[1], v1[2], v1[3]);
-                    if (second) *reinterpret_cast<float4*>(i1 + N + 4 * q) = make_float4(v2[0], v2[1], v2[2], v2[3]);
-                }
-            });
+        auto emit4 = [&](int q, const float (&xa)[4], const float (&v1)[4], const float (&xb)[4], const float (&v2)[4]) {
+            using stof_io::envelope;
+            if (e1) {
+                *reinterpret_cast<float4*>(e1 + 4 * q) = make_float4(envelope(xa[0], v1[0]), envelope(xa[1], v1[1]),
+                                                                     envelope(xa[2], v1[2]), envelope(xa[3], v1[3]));
+                if (second)
+                    *reinterpret_cast<float4*>(e1 + N + 4 * q) = make_float4(envelope(xb[0], v2[0]), envelope(xb[1], v2[1]),
+                                                                             envelope(xb[2], v2[2]), envelope(xb[3], v2[3]));
+            }
+            if (r1) {
+                *reinterpret_cast<float4*>(r1 + 4 * q) = make_float4(xa[0], xa[1], xa[2], xa[3]);
+                if (second) *reinterpret_cast<float4*>(r1 + N + 4 * q) = make_float4(xb[0], xb[1], xb[2], xb[3]);
+            }
+            if (i1) {
+                *reinterpret_cast<float4*>(i1 + 4 * q) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+                if (second) *reinterpret_cast<float4*>(i1 + N + 4 * q) = make_float4(v2[0], v2[1], v2[2], v2[3]);
+            }
+        };
+        if constexpr (KEEP) stof_io::unmix_pair_regs<IO, PAD>(Z, cur, N, tid, T, emit4);
+        else stof_io::unmix_pair<4>(Z, xrow, xrow2, N, tid, T, emit4, [](int, float, float, float, float) {});   // (rows are 16-byte aligned here)
         fetch(cur, pr + stride);                                   // next pair's rows (its latency hides behind the stores)
     }
 }
 
-template <int N, int WPP, int PPW>
+template <int N, int WPP, int PPW, bool PAD = true, bool TW2 = false, bool KEEP = true>
 int launch_ct(const float* x, int64_t nrows, float* env, float* re, float* im, int ncu, hipStream_t stream) {
-    constexpr size_t lds = ((size_t)(CtTwiddles<N>::K + 1) / 2 * 2 + (size_t)PPW * stof_fft::ct_slot_entries(N)) * sizeof(float2);
+    constexpr size_t lds = ((size_t)(TW2 ? stof_ct::twiddle2_lds_entries<N>() : stof_ct::twiddle_lds_entries<N>()) +
+                            (size_t)PPW * (PAD ? stof_fft::ct_slot_entries(N) : N)) * sizeof(float2);
     static_assert(lds <= (size_t)LDS_BYTES, "slots + table exceed LDS");
     static stof::LdsLimitOnce once;
-    if (int st = once.ensure(reinterpret_cast<const void*>(&hilbert_ct_kernel<N, WPP, PPW>), LDS_BYTES)) return st;
+    if (int st = once.ensure(reinterpret_cast<const void*>(&hilbert_ct_kernel<N, WPP, PPW, PAD, TW2, KEEP>), LDS_BYTES)) return st;
     const int64_t npairs = (nrows + 1) / 2, groups = (npairs + PPW - 1) / PPW;
     int64_t grid = (int64_t)ncu * (int64_t)((size_t)LDS_BYTES / lds);
     if (grid > groups) grid = groups;
-    hipLaunchKernelGGL((hilbert_ct_kernel<N, WPP, PPW>), dim3((unsigned)grid), dim3(64 * WPP * PPW), lds, stream, x,
+    hipLaunchKernelGGL((hilbert_ct_kernel<N, WPP, PPW, PAD, TW2, KEEP>), dim3((unsigned)grid), dim3(64 * WPP * PPW), lds, stream, x,
                        (long long)nrows, env, re, im);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
@@ -446,6 +456,8 @@ int try_launch_ct(const float* x, int64_t nrows, int64_t n, float* env, float* r
         case 4000: return launch_ct<4000, 2, 2>(x, nrows, env, re, im, ncu, stream);
         case 4096: return launch_ct<4096, 2, 2>(x, nrows, env, re, im, ncu, stream);
         case 8000: return launch_ct<8000, 4, 2>(x, nrows, env, re, im, ncu, stream);
+        // 20,000 values = 160,000 bytes: the image alone nearly fills LDS -> unpadded, two-level twiddles, eight waves per pair
+        case 20000: return launch_ct<20000, 8, 1, false, true, false>(x, nrows, env, re, im, ncu, stream);
         default: return -1;
     }
 }

@@ -121,3 +121,32 @@ extern "C" int fft_ct_table(int n, float* out) {
     if (n == 1536) { static constexpr TwTable<256> t = make_tw_table<1536, 256>(); for (int k = 0; k < 256; ++k) { out[2 * k] = t.w[k].x; out[2 * k + 1] = t.w[k].y; } return 256; }
     return 0;
 }
+
+// the unpadded layout with the two-level twiddle table (rows whose padded image does not fit LDS)
+template <int N, int T, int S, int M>
+static void host_level2(cf* Z, const cf* W) {
+    using OPT = CtOpt<false, true>;
+    constexpr CtPlan P = ct_plan_for(N);
+    if constexpr (S < P.npass) {
+        constexpr int R = P.radix[S];
+        for (int tid = 0; tid < T; ++tid) ct_pass<N, M, R, false, T, OPT>(Z, W, tid);
+        host_level2<N, T, S + 1, M / R>(Z, W);
+        for (int tid = 0; tid < T; ++tid) ct_pass<N, M, R, true, T, OPT>(Z, W, tid);
+    } else {
+        for (int tid = 0; tid < T; ++tid) ct_middle16<N, T, OPT>(Z, tid, ct_filter_default<N>());
+    }
+}
+template <int N, int T>
+static int run_ct2(float* z) {
+    static constexpr auto table = make_tw_table2<N>();
+    host_level2<N, T, 0, N>(reinterpret_cast<cf*>(z), reinterpret_cast<const cf*>(table.w));
+    return 1;
+}
+extern "C" int fft_analytic_ct_plain(int n, float* z) {
+    switch (n) {
+        case 2000: return run_ct2<2000, 64>(z);
+        case 8000: return run_ct2<8000, 256>(z);
+        case 20000: return run_ct2<20000, 512>(z);
+    }
+    return 0;
+}

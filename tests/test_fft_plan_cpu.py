@@ -25,6 +25,7 @@ def harness(tmp_path_factory):
     lib.fft_butterfly.argtypes = [ctypes.c_int, ctypes.c_void_p]
     lib.fft_analytic_ct.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     lib.fft_ct_table.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    lib.fft_analytic_ct_plain.argtypes = [ctypes.c_int, ctypes.c_void_p]
     lib.fft_ct_plan.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     return lib
 
@@ -119,3 +120,19 @@ def test_compile_time_plan_shapes(harness):
     assert ct_plan(4096) == ([16, 16], 256)
     assert ct_plan(16) == ([], 1)
     assert ct_plan(2008) is None and ct_plan(112) is None and ct_plan(24) is None
+
+
+@pytest.mark.parametrize('n', [2000, 8000, 20000])
+def test_compile_time_plan_plain_layout_two_level_twiddles(harness, n):
+    """CtOpt<PAD = false, TW2 = true>: the unpadded image and the two-level twiddle table used when the padded image of a
+    row (20,000 values) would not fit LDS."""
+    rng = np.random.default_rng(n + 11)
+    x1 = rng.standard_normal(n)
+    x2 = rng.standard_normal(n)
+    x1 /= np.abs(x1).max()
+    x2 /= np.abs(x2).max()
+    z = (x1 + 1j * x2).astype(np.complex64)
+    buf = z.copy()
+    assert harness.fft_analytic_ct_plain(n, buf.ctypes.data)
+    want = po.hilbert_transform(x1.astype(np.float32)) + 1j * po.hilbert_transform(x2.astype(np.float32))
+    assert np.abs(buf - want).max() < 1e-5 * max(1.0, np.log2(n) / 8)
