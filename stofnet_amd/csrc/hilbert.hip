@@ -455,7 +455,9 @@ int try_launch_ct(const float* x, int64_t nrows, int64_t n, float* env, float* r
         case 2048: return launch_ct<2048, 1, 4>(x, nrows, env, re, im, ncu, stream);
         case 4000: return launch_ct<4000, 2, 2>(x, nrows, env, re, im, ncu, stream);
         case 4096: return launch_ct<4096, 2, 2>(x, nrows, env, re, im, ncu, stream);
+        case 6144: return launch_ct<6144, 4, 2>(x, nrows, env, re, im, ncu, stream);          // PALA frames (1536) x rf 4
         case 8000: return launch_ct<8000, 4, 2>(x, nrows, env, re, im, ncu, stream);
+        case 15360: return launch_ct<15360, 8, 1>(x, nrows, env, re, im, ncu, stream);        // PALA frames x rf 10
         // 20,000 values = 160,000 bytes: the image alone nearly fills LDS -> unpadded, two-level twiddles, eight waves per pair
         case 20000: return launch_ct<20000, 8, 1, false, true, false>(x, nrows, env, re, im, ncu, stream);
         default: return -1;

@@ -390,7 +390,7 @@ def test_hilbert_more_lengths_vs_oracle(dev, n):
     assert np.abs(env - po.hilbert_envelope(x)).max() < ENV_TOL
 
 
-@pytest.mark.parametrize('n', [1536, 2000, 2048, 4000, 4096, 8000, 20000])
+@pytest.mark.parametrize('n', [1536, 2000, 2048, 4000, 4096, 6144, 8000, 15360, 20000])
 @pytest.mark.parametrize('rows', [1, 2, 7, 1030])
 def test_hilbert_compile_time_plan_lengths(dev, n, rows):
     """Row lengths served by the compile-time plans (hilbert_ct_kernel): odd batches leave a lone row in the last pair,

@@ -92,7 +92,9 @@ CASES = {
     'hilbert_4096x2048': lambda: case_hilbert(4096, 2048),
     'hilbert_4096x4000': lambda: case_hilbert(4096, 4000),
     'hilbert_4096x4096': lambda: case_hilbert(4096, 4096),
+    'hilbert_4096x6144': lambda: case_hilbert(4096, 6144),
     'hilbert_4096x8000': lambda: case_hilbert(4096, 8000),
+    'hilbert_2048x15360': lambda: case_hilbert(2048, 15360),
     'hilbert_1024x20000': lambda: case_hilbert(1024, 20000),
     'hilbert_512x30720': lambda: case_hilbert(512, 30720),
     'gradpeak_fused_4096x2000_rf10_th1em3': lambda: case_gradpeak(4096, 2000, 10, 1e-3),
