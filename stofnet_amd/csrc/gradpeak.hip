@@ -341,10 +341,14 @@ __global__ __launch_bounds__(256, 4) void toa_fused_kernel(const FusedParams p) 
     }
 }
 
-constexpr int FUSED_MAX_L = 4096;      // beyond this the envelope kernel + row-streaming kernel parallelise better
+// Beyond this the envelope kernel + row-streaming kernel are faster: with the compile-time-plan Hilbert kernels the two
+// launches take 46.8 + 67.0 us on [4096, 4000] against 160 us fused (run-time plan transform inside), and 25.9 + 35.1 us
+// against 64 us on [4096, 2000], where the single launch is kept for its lower host overhead and no envelope buffer.
+constexpr int FUSED_MAX_L = 2048;
 
 size_t fused_lds_bytes(int64_t n, int radius, stof_fft::Plan* plan) {
-    if (n > FUSED_MAX_L || !stof::hilbert_fast_lds_bytes(n, plan)) return 0;
+    static const int64_t max_l = [] { const char* e = getenv("STOF_FUSED_MAX_L"); return e ? (int64_t)atoll(e) : (int64_t)FUSED_MAX_L; }();
+    if (n > max_l || !stof::hilbert_fast_lds_bytes(n, plan)) return 0;
     return ((size_t)n + stof_fft::twiddle_entries((int)n) + 1) * sizeof(float2) +
            ((size_t)stof_gp::TAPS_LDS + 2 * stof_gp::ring_floats(radius)) * sizeof(float);
 }
