@@ -195,6 +195,12 @@ int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, float* re, fl
  * all-reduced values of a sharded batch -- into stats[0..2] = (sum, sum of squares, count)).                        */
 int stof_gradpeak_moments(const float* env, int64_t N, int64_t L, int32_t grad_step, const float* taps,
                           int32_t radius, double* stats, void* stream);
+/* The same pre-pass that also keeps what it computed: blurred[N, stof_gradpeak_blurred_stride(L, radius)] receives the
+ * smoothed gradient of every row (in the kernels' streaming order, zero outside the row), so that the detection after
+ * the threshold is known does not redo gradient and blur (stof_grad_peak_detect_blurred).                            */
+int64_t stof_gradpeak_blurred_stride(int64_t L, int32_t radius);
+int stof_gradpeak_moments_store(const float* env, int64_t N, int64_t L, int32_t grad_step, const float* taps,
+                                int32_t radius, double* stats, float* blurred, void* stream);
 /* thres_pos = std**16 * 1.2e13 (:18) from stats[3] = (sum, sum of squares, count) into threshold_out[0], on the device. */
 int stof_gradpeak_threshold(const double* stats, float* threshold_out, void* stream);
 
@@ -205,6 +211,13 @@ int stof_grad_peak_detect(const float* env, int64_t N, int64_t L, int32_t grad_s
                           int32_t radius, float threshold, const float* threshold_dev, int32_t ival_min,
                           int32_t ival_max, int64_t echo_max, float* echoes, int64_t cap, float* reduced,
                           int32_t* counts, int32_t* flags, void* stream);
+
+/* grad_peak_detect from the smoothed gradient kept by stof_gradpeak_moments_store: threshold crossings and pairing only
+ * (env supplies the amplitudes of the kept peaks).  Same outputs as stof_grad_peak_detect.                            */
+int stof_grad_peak_detect_blurred(const float* env, const float* blurred, int64_t N, int64_t L, int32_t radius,
+                                  float threshold, const float* threshold_dev, int32_t ival_min, int32_t ival_max,
+                                  int64_t echo_max, float* echoes, int64_t cap, float* reduced, int32_t* counts,
+                                  int32_t* flags, void* stream);
 
 /* toa_detect (models/gradpeak.py:99-116) with an explicit threshold in ONE launch on waveforms frame[N, L]:
  * Hilbert envelope (utils/hilbert.py:5-21) -> grad_peak_detect -> echo_max reduction; the envelope stays in LDS

@@ -74,6 +74,12 @@ _SIGNATURES = {
                                 _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     'stof_gradpeak_moments': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32,
                                          _c.c_void_p, _c.c_void_p]),
+    'stof_gradpeak_blurred_stride': (_c.c_int64, [_c.c_int64, _c.c_int32]),
+    'stof_gradpeak_moments_store': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32,
+                                               _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'stof_grad_peak_detect_blurred': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_float,
+                                                 _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_int64, _c.c_void_p, _c.c_int64,
+                                                 _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'stof_gradpeak_threshold': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'stof_grad_peak_detect': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32,
                                          _c.c_float, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_int64, _c.c_void_p,

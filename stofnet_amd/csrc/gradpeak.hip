@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * WAVES) void gradpeak_rows_kernel(const float* 
                                                                         const float* __restrict__ th_dev,
                                                                         float* __restrict__ echoes, float* __restrict__ reduced,
                                                                         int* __restrict__ counts, int* __restrict__ flags,
-                                                                        double* __restrict__ stats) {
+                                                                        double* __restrict__ stats, float* __restrict__ blurred) {
     __shared__ __attribute__((aligned(16))) float tp[stof_gp::TAPS_LDS];
     __shared__ float rings[WAVES][512];
     __shared__ double red[2][WAVES];
@@ -55,6 +55,17 @@ __global__ __launch_bounds__(64 * WAVES) void gradpeak_rows_kernel(const float* 
         const float* e = env + row * (long long)cf.L;
         float* const out[1] = {MOMENTS ? nullptr : echoes + row * cf.cap * 3};
         RowState st[1];
+        if (MOMENTS && blurred != nullptr) {                   // keep the smoothed gradient for stof_grad_peak_detect_blurred
+            const int nw = stof_gp::word_count(cf.L, cf.radius);
+            float* const b = blurred + row * (long long)nw * 64;
+            stof_gp::stream_words<1>(cf, tp, rings[wave], lane, [&](int u, float (&v)[1]) { v[0] = e[u]; }, 0, nw - 1, true,
+                                     [&](int c, int, unsigned long long, unsigned long long, unsigned long long, float sm) {
+                                         mom[0] += (double)sm;
+                                         mom[1] += (double)sm * (double)sm;
+                                         b[64 * c + lane] = sm;
+                                     });
+            continue;
+        }
         stof_gp::stream_rows<1, MOMENTS>(
             cf, tp, rings[wave], lane, [&](int u, float (&v)[1]) { v[0] = e[u]; }, [&](int, int i) { return e[i]; }, out, st, mom);
         if constexpr (!MOMENTS) {
@@ -241,6 +252,59 @@ bool launch_split(const float* env, int64_t N, const Config& cf, const float* ta
     return true;
 }
 
+// Detection from the smoothed gradient kept by the moments pass (row-major, 64 values per iteration): the loads do not
+// depend on anything computed here, so several iterations are requested ahead; flags, edges and pairing as in stream_rows.
+__global__ __launch_bounds__(64 * ROWS_WAVES) void gradpeak_flags_kernel(const float* __restrict__ env, const float* __restrict__ blurred,
+                                                                         long long N, Config cf, const float* __restrict__ th_dev,
+                                                                         float* __restrict__ echoes, float* __restrict__ reduced,
+                                                                         int* __restrict__ counts, int* __restrict__ flags) {
+    __shared__ int wmax[ROWS_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (th_dev != nullptr) {
+        cf.th_pos = *th_dev;
+        cf.th_neg = -cf.th_pos / 4.0f;                          // models/gradpeak.py:19
+    }
+    const int L = cf.L, rad = cf.radius, nw = stof_gp::word_count(L, rad);
+    constexpr int AHEAD = 8;
+    int kmax = 0;
+    for (long long row = (long long)blockIdx.x * ROWS_WAVES + wave; row < N; row += (long long)gridDim.x * ROWS_WAVES) {
+        const float* const b = blurred + row * (long long)nw * 64 + lane;
+        const float* const e = env + row * (long long)L;
+        float* const out = echoes + row * cf.cap * 3;
+        RowState st;
+        for (int c0 = 0; c0 < nw; c0 += AHEAD) {
+            float sm[AHEAD];
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) sm[k] = (c0 + k < nw) ? b[64 * (c0 + k)] : 0.f;
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                const int c = c0 + k;
+                if (c >= nw) break;
+                const int i = 64 * c + lane - rad;
+                const bool in_row = (i >= 0) && (i < L);
+                const unsigned long long V = __ballot(in_row && i < L - 1);
+                const unsigned long long P = __ballot(in_row && sm[k] > cf.th_pos);
+                const unsigned long long M = __ballot(in_row && sm[k] < cf.th_neg);
+                if (c > 0) {
+                    const unsigned long long EP = ~st.P & ((st.P >> 1) | (P << 63)) & st.V;
+                    const unsigned long long EM = ~st.M & ((st.M >> 1) | (M << 63)) & st.V;
+                    stof_gp::pair_word(st, 64 * (c - 1) - rad, EP, EM, lane, cf, out, [&](int idx) { return e[idx]; });
+                }
+                st.P = P; st.M = M; st.V = V;
+            }
+        }
+        stof_gp::finish_row(st, cf, row, out, reduced, counts, flags, lane, true);
+        kmax = st.nout > kmax ? st.nout : kmax;
+    }
+    if (lane == 0) wmax[wave] = kmax;
+    __syncthreads();
+    if (tid == 0) {
+        int m = 0;
+        for (int w = 0; w < ROWS_WAVES; ++w) m = wmax[w] > m ? wmax[w] : m;
+        if (m > 0 && m > __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[1], m);
+    }
+}
+
 // thres_pos = (grad_data.std() ** 16) * 1.2e13 (models/gradpeak.py:18): unbiased std of all N * L smoothed gradients
 // from stats = (sum, sum of squares, count), rounded to fp32 where torch rounds (std is an fp32 tensor, the power and
 // the product are fp32 operations); the 16th power is taken in double and rounded once (= a correctly rounded powf).
@@ -387,7 +451,26 @@ extern "C" int stof_gradpeak_moments(const float* env, int64_t N, int64_t L, int
     if (grid > maxg) grid = maxg;
     hipLaunchKernelGGL((gradpeak_rows_kernel<true, MOMENT_WAVES>), dim3((unsigned)grid), dim3(64 * MOMENT_WAVES), 0,
                        static_cast<hipStream_t>(stream), env, (long long)N, cf, taps, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       stats);
+                       stats, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int64_t stof_gradpeak_blurred_stride(int64_t L, int32_t radius) {
+    return (L <= 0 || radius < 0) ? 0 : (int64_t)stof_gp::word_count((int)L, radius) * 64;
+}
+
+extern "C" int stof_gradpeak_moments_store(const float* env, int64_t N, int64_t L, int32_t grad_step, const float* taps,
+                                           int32_t radius, double* stats, float* blurred, void* stream) {
+    if (!env || !taps || !stats || !blurred || bad_common(N, L, grad_step, radius, 0)) return STOF_ERR_BAD_ARG;
+    if (N == 0 || L == 0) return STOF_OK;
+    if (radius > stof_gp::MAXRAD || L > 0x3fffffffLL) return STOF_ERR_UNSUPPORTED;
+    const Config cf = make_config(L, grad_step, radius, 0.f, 0, 0, 0, 0);
+    int64_t grid = (N + MOMENT_WAVES - 1) / MOMENT_WAVES;
+    const int64_t maxg = (int64_t)stof::device_cu_count() * 2;
+    if (grid > maxg) grid = maxg;
+    hipLaunchKernelGGL((gradpeak_rows_kernel<true, MOMENT_WAVES>), dim3((unsigned)grid), dim3(64 * MOMENT_WAVES), 0,
+                       static_cast<hipStream_t>(stream), env, (long long)N, cf, taps, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       stats, blurred);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
@@ -418,7 +501,25 @@ extern "C" int stof_grad_peak_detect(const float* env, int64_t N, int64_t L, int
     if (grid > maxg) grid = maxg;
     hipLaunchKernelGGL((gradpeak_rows_kernel<false, ROWS_WAVES>), dim3((unsigned)grid), dim3(64 * ROWS_WAVES), 0,
                        static_cast<hipStream_t>(stream), env, (long long)N, cf, taps, threshold_dev, echoes, reduced, counts, flags,
-                       nullptr);
+                       nullptr, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_grad_peak_detect_blurred(const float* env, const float* blurred, int64_t N, int64_t L, int32_t radius,
+                                             float threshold, const float* threshold_dev, int32_t ival_min, int32_t ival_max,
+                                             int64_t echo_max, float* echoes, int64_t cap, float* reduced, int32_t* counts,
+                                             int32_t* flags, void* stream) {
+    if (!env || !blurred || !counts || !flags || (!echoes && cap > 0) || bad_common(N, L, 1, radius, cap)) return STOF_ERR_BAD_ARG;
+    if (echo_max > 0 && !reduced) return STOF_ERR_BAD_ARG;
+    if (N == 0) return STOF_OK;
+    if (radius > stof_gp::MAXRAD || L > 0x3fffffffLL || N > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    const Config cf = make_config(L, 1, radius, threshold, ival_min, ival_max, cap, echo_max);
+    if (hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return STOF_ERR_HIP;
+    int64_t grid = (N + ROWS_WAVES - 1) / ROWS_WAVES;
+    const int64_t maxg = (int64_t)stof::device_cu_count() * 8;
+    if (grid > maxg) grid = maxg;
+    hipLaunchKernelGGL(gradpeak_flags_kernel, dim3((unsigned)grid), dim3(64 * ROWS_WAVES), 0, static_cast<hipStream_t>(stream), env,
+                       blurred, (long long)N, cf, threshold_dev, echoes, reduced, counts, flags);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

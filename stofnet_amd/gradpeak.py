@@ -8,6 +8,7 @@ import torch
 from . import _lib
 from .hilbert import hilbert_envelope
 
+_KEEP_BLURRED_MIN_ROWS = 3072        # 12 rows per CU of an MI355X: below that the split rows kernel serves both passes
 _CAP = 32          # echoes per row kept by the first pass; rows with more trigger a re-run
 
 
@@ -60,14 +61,22 @@ def _detect(frame_or_env, is_frame, grad_step, threshold, ival, echo_max, group=
     fused = bool(is_frame and threshold is not None and lib.stof_toa_detect_fused_ok(L, radius))
     env = None
     th_dev = None
+    blurred = None
     with torch.cuda.device(x.device):
         if not fused:
             env = hilbert_envelope(x) if is_frame else x
             if threshold is None:
                 # Q7: (unbiased std of the WHOLE batch tensor) ** 16 * 1.2e13 (models/gradpeak.py:18), formed on the device
                 stats = torch.tensor([0.0, 0.0, float(n * L)], dtype=torch.float64, device=x.device)
-                _lib.check(lib.stof_gradpeak_moments(_lib.ptr(env), n, L, int(grad_step), _lib.ptr(taps), radius,
-                                                     _lib.ptr(stats), stream), 'stof_gradpeak_moments')
+                if n >= _KEEP_BLURRED_MIN_ROWS:
+                    # enough rows for one wave per row: the pre-pass keeps the smoothed gradient and the detection below
+                    # only thresholds and pairs it (rows of the two passes would otherwise be differentiated and blurred twice)
+                    blurred = torch.empty((n, lib.stof_gradpeak_blurred_stride(L, radius)), dtype=torch.float32, device=x.device)
+                    _lib.check(lib.stof_gradpeak_moments_store(_lib.ptr(env), n, L, int(grad_step), _lib.ptr(taps), radius,
+                                                               _lib.ptr(stats), _lib.ptr(blurred), stream), 'stof_gradpeak_moments_store')
+                else:
+                    _lib.check(lib.stof_gradpeak_moments(_lib.ptr(env), n, L, int(grad_step), _lib.ptr(taps), radius,
+                                                         _lib.ptr(stats), stream), 'stof_gradpeak_moments')
                 _moment_reduce(stats, group)
                 th_dev = torch.empty(1, dtype=torch.float32, device=x.device)
                 _lib.check(lib.stof_gradpeak_threshold(_lib.ptr(stats), _lib.ptr(th_dev), stream), 'stof_gradpeak_threshold')
@@ -82,6 +91,10 @@ def _detect(frame_or_env, is_frame, grad_step, threshold, ival, echo_max, group=
                 code = lib.stof_toa_detect(_lib.ptr(x), n, L, int(grad_step), _lib.ptr(taps), radius, th, ival[0], ival[1],
                                            emax, _lib.ptr(echoes), cap, _lib.ptr(reduced), _lib.ptr(counts),
                                            _lib.ptr(flags), None, stream)
+            elif blurred is not None:
+                code = lib.stof_grad_peak_detect_blurred(_lib.ptr(env), _lib.ptr(blurred), n, L, radius, th, _lib.ptr(th_dev),
+                                                         ival[0], ival[1], emax, _lib.ptr(echoes), cap, _lib.ptr(reduced),
+                                                         _lib.ptr(counts), _lib.ptr(flags), stream)
             else:
                 code = lib.stof_grad_peak_detect(_lib.ptr(env), n, L, int(grad_step), _lib.ptr(taps), radius, th,
                                                  _lib.ptr(th_dev), ival[0], ival[1], emax, _lib.ptr(echoes), cap,

@@ -21,7 +21,7 @@ def lib():
 
 def test_exports_match_header(lib):
     hdr = open(os.path.join(ROOT, 'include', 'stofnet_amd.h')).read()
-    declared = set(re.findall(r'^(?:int|size_t|const char\*)\s+(stof_[a-z0-9_]+)\s*\(', hdr, flags=re.M))
+    declared = set(re.findall(r'^(?:int|int64_t|size_t|const char\*)\s+(stof_[a-z0-9_]+)\s*\(', hdr, flags=re.M))
     assert declared, 'no declarations found'
     for sym in sorted(declared):
         assert hasattr(lib, sym), f'{sym} declared in include/stofnet_amd.h but not exported'

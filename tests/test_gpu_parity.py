@@ -508,6 +508,27 @@ def test_gradpeak_1024_rows_exact_vs_reference(dev, rf, thn, th):
     assert np.array_equal(em3[same], g[f'em3_rf{rf}_th{thn}'][same])
 
 
+@pytest.mark.parametrize('rf', [10, 20])
+def test_gradpeak_default_threshold_with_kept_blurred_gradient(dev, rf, monkeypatch):
+    """Large batches keep the smoothed gradient of the moments pre-pass and only threshold / pair it afterwards
+    (stof_gradpeak_moments_store + stof_grad_peak_detect_blurred): same result as differentiating and blurring twice,
+    and the reference's indices on the 1024-row golden (rows the float64 oracle marks borderline excepted)."""
+    import stofnet_amd.gradpeak as gp
+    from stofnet_amd import toa_detect
+    g = golden('f9_gradpeak_1024')
+    L, seed = int(g[f'L_rf{rf}']), int(g[f'seed_rf{rf}'])
+    x = torch.from_numpy(synth.synth_echo(1024, L, seed=seed, noise=0.01)).to(dev).squeeze(1)
+    a = toa_detect(x, threshold=None, rescale_factor=rf).cpu().numpy()
+    monkeypatch.setattr(gp, '_KEEP_BLURRED_MIN_ROWS', 1)
+    b = toa_detect(x, threshold=None, rescale_factor=rf).cpu().numpy()
+    assert a.shape == b.shape and np.array_equal(a, b)
+    idx = g[f'idx_rf{rf}_thnone']
+    differs = (b[..., :2] != idx).any(axis=(1, 2))
+    assert differs.sum() <= 2 and not (differs & ~borderline_rows(x.cpu().numpy(), None, rf)).any()
+    e3 = gp.GradPeak(threshold=None, rescale_factor=rf, echo_max=3, onset_opt=False)(x.unsqueeze(1)).cpu().numpy()
+    assert np.array_equal(e3[~differs], g[f'em3_rf{rf}_thnone'][~differs])
+
+
 @pytest.mark.parametrize('W', [1, 2, 4])
 def test_gradpeak_split_kernel_matches_row_kernel(dev, W, monkeypatch):
     """gradpeak_split_kernel (rows split over W waves, envelope staged through LDS, stored flag words paired afterwards)
