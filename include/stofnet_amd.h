@@ -175,6 +175,11 @@ int stof_reduce_echoes(const float* scores, int64_t N, int64_t M, const int32_t*
 size_t stof_hilbert_workspace_bytes(int64_t N, int64_t n);
 int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, float* re, float* im,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* The same call for an output that nobody reads again soon (a result handed back to the framework): the envelope is
+ * written with non-temporal stores and stays out of L2 / Infinity Cache ([4096,2000]: 23.9 -> 21.6 us).  A consumer that
+ * follows immediately (GradPeak's row kernels) is better served by stof_hilbert, whose output it finds in the cache.  */
+int stof_hilbert_streamed(const float* x, int64_t N, int64_t n, float* env, float* re, float* im,
+                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * GradPeak (models/gradpeak.py).  Common arguments:

@@ -357,7 +357,9 @@ using stof_ct::CtTwiddles;
 
 // PAD / TW2: fft_small.h's CtOpt (rows whose padded image or full twiddle table would not fit LDS go without)
 // KEEP: the pair's rows stay in registers from the load to the un-mixing (otherwise they are read a second time)
-template <int N, int WPP, int PPW, bool PAD = true, bool TW2 = false, bool KEEP = true>
+// NT: the envelope is written with non-temporal stores (a compile-time choice: behind a run-time flag the compiler merges
+// the two stores into a plain one)
+template <int N, int WPP, int PPW, bool PAD = true, bool TW2 = false, bool KEEP = true, bool NT = false>
 __global__ __launch_bounds__(64 * WPP * PPW) void hilbert_ct_kernel(const float* __restrict__ x, long long nrows,
                                                                      float* __restrict__ env, float* __restrict__ re,
                                                                      float* __restrict__ im) {
@@ -406,11 +408,16 @@ __global__ __launch_bounds__(64 * WPP * PPW) void hilbert_ct_kernel(const float*
         auto emit4 = [&](int q, const float (&xa)[4], const float (&v1)[4], const float (&xb)[4], const float (&v2)[4]) {
             using stof_io::envelope;
             if (e1) {
-                *reinterpret_cast<float4*>(e1 + 4 * q) = make_float4(envelope(xa[0], v1[0]), envelope(xa[1], v1[1]),
-                                                                     envelope(xa[2], v1[2]), envelope(xa[3], v1[3]));
-                if (second)
-                    *reinterpret_cast<float4*>(e1 + N + 4 * q) = make_float4(envelope(xb[0], v2[0]), envelope(xb[1], v2[1]),
-                                                                             envelope(xb[2], v2[2]), envelope(xb[3], v2[3]));
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f ea = {envelope(xa[0], v1[0]), envelope(xa[1], v1[1]), envelope(xa[2], v1[2]), envelope(xa[3], v1[3])};
+                const v4f eb = {envelope(xb[0], v2[0]), envelope(xb[1], v2[1]), envelope(xb[2], v2[2]), envelope(xb[3], v2[3])};
+                if constexpr (NT) {                            // write-once output nobody reads soon: keep it out of the caches
+                    __builtin_nontemporal_store(ea, reinterpret_cast<v4f*>(e1 + 4 * q));
+                    if (second) __builtin_nontemporal_store(eb, reinterpret_cast<v4f*>(e1 + N + 4 * q));
+                } else {
+                    *reinterpret_cast<v4f*>(e1 + 4 * q) = ea;
+                    if (second) *reinterpret_cast<v4f*>(e1 + N + 4 * q) = eb;
+                }
             }
             if (r1) {
                 *reinterpret_cast<float4*>(r1 + 4 * q) = make_float4(xa[0], xa[1], xa[2], xa[3]);
@@ -428,38 +435,44 @@ __global__ __launch_bounds__(64 * WPP * PPW) void hilbert_ct_kernel(const float*
 }
 
 template <int N, int WPP, int PPW, bool PAD = true, bool TW2 = false, bool KEEP = true>
-int launch_ct(const float* x, int64_t nrows, float* env, float* re, float* im, int ncu, hipStream_t stream) {
+int launch_ct(const float* x, int64_t nrows, float* env, float* re, float* im, int ncu, hipStream_t stream, int streamed) {
     constexpr size_t lds = ((size_t)(TW2 ? stof_ct::twiddle2_lds_entries<N>() : stof_ct::twiddle_lds_entries<N>()) +
                             (size_t)PPW * (PAD ? stof_fft::ct_slot_entries(N) : N)) * sizeof(float2);
     static_assert(lds <= (size_t)LDS_BYTES, "slots + table exceed LDS");
-    static stof::LdsLimitOnce once;
-    if (int st = once.ensure(reinterpret_cast<const void*>(&hilbert_ct_kernel<N, WPP, PPW, PAD, TW2, KEEP>), LDS_BYTES)) return st;
+    static stof::LdsLimitOnce once[2];
+    const void* const kern = streamed ? reinterpret_cast<const void*>(&hilbert_ct_kernel<N, WPP, PPW, PAD, TW2, KEEP, true>)
+                                      : reinterpret_cast<const void*>(&hilbert_ct_kernel<N, WPP, PPW, PAD, TW2, KEEP, false>);
+    if (int st = once[streamed ? 1 : 0].ensure(kern, LDS_BYTES)) return st;
     const int64_t npairs = (nrows + 1) / 2, groups = (npairs + PPW - 1) / PPW;
     int64_t grid = (int64_t)ncu * (int64_t)((size_t)LDS_BYTES / lds);
     if (grid > groups) grid = groups;
-    hipLaunchKernelGGL((hilbert_ct_kernel<N, WPP, PPW, PAD, TW2, KEEP>), dim3((unsigned)grid), dim3(64 * WPP * PPW), lds, stream, x,
-                       (long long)nrows, env, re, im);
+    if (streamed)
+        hipLaunchKernelGGL((hilbert_ct_kernel<N, WPP, PPW, PAD, TW2, KEEP, true>), dim3((unsigned)grid), dim3(64 * WPP * PPW), lds,
+                           stream, x, (long long)nrows, env, re, im);
+    else
+        hipLaunchKernelGGL((hilbert_ct_kernel<N, WPP, PPW, PAD, TW2, KEEP, false>), dim3((unsigned)grid), dim3(64 * WPP * PPW), lds,
+                           stream, x, (long long)nrows, env, re, im);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
 // lengths with a compile-time plan; returns -1 if n has none (or STOF_HILBERT_CT=0 asks for the run-time plan)
-int try_launch_ct(const float* x, int64_t nrows, int64_t n, float* env, float* re, float* im, int ncu, hipStream_t stream) {
+int try_launch_ct(const float* x, int64_t nrows, int64_t n, float* env, float* re, float* im, int ncu, hipStream_t stream, int streamed) {
     static const int mode = [] { const char* e = getenv("STOF_HILBERT_CT"); return e ? atoi(e) : 1; }();
     if (mode == 0) return -1;
     for (const void* p : {(const void*)x, (const void*)env, (const void*)re, (const void*)im})
         if (reinterpret_cast<size_t>(p) & 15) return -1;        // 16-byte row accesses
     switch (n) {
         // one wave per pair up to 2048 samples (16 register-resident 16-byte pieces per lane), two waves beyond
-        case 1536: return launch_ct<1536, 1, 4>(x, nrows, env, re, im, ncu, stream);
-        case 2000: return launch_ct<2000, 1, 4>(x, nrows, env, re, im, ncu, stream);
-        case 2048: return launch_ct<2048, 1, 4>(x, nrows, env, re, im, ncu, stream);
-        case 4000: return launch_ct<4000, 2, 2>(x, nrows, env, re, im, ncu, stream);
-        case 4096: return launch_ct<4096, 2, 2>(x, nrows, env, re, im, ncu, stream);
-        case 6144: return launch_ct<6144, 4, 2>(x, nrows, env, re, im, ncu, stream);          // PALA frames (1536) x rf 4
-        case 8000: return launch_ct<8000, 4, 2>(x, nrows, env, re, im, ncu, stream);
-        case 15360: return launch_ct<15360, 8, 1>(x, nrows, env, re, im, ncu, stream);        // PALA frames x rf 10
+        case 1536: return launch_ct<1536, 1, 4>(x, nrows, env, re, im, ncu, stream, streamed);
+        case 2000: return launch_ct<2000, 1, 4>(x, nrows, env, re, im, ncu, stream, streamed);
+        case 2048: return launch_ct<2048, 1, 4>(x, nrows, env, re, im, ncu, stream, streamed);
+        case 4000: return launch_ct<4000, 2, 2>(x, nrows, env, re, im, ncu, stream, streamed);
+        case 4096: return launch_ct<4096, 2, 2>(x, nrows, env, re, im, ncu, stream, streamed);
+        case 6144: return launch_ct<6144, 4, 2>(x, nrows, env, re, im, ncu, stream, streamed);          // PALA frames (1536) x rf 4
+        case 8000: return launch_ct<8000, 4, 2>(x, nrows, env, re, im, ncu, stream, streamed);
+        case 15360: return launch_ct<15360, 8, 1>(x, nrows, env, re, im, ncu, stream, streamed);        // PALA frames x rf 10
         // 20,000 values = 160,000 bytes: the image alone nearly fills LDS -> unpadded, two-level twiddles, eight waves per pair
-        case 20000: return launch_ct<20000, 8, 1, false, true, false>(x, nrows, env, re, im, ncu, stream);
+        case 20000: return launch_ct<20000, 8, 1, false, true, false>(x, nrows, env, re, im, ncu, stream, streamed);
         default: return -1;
     }
 }
@@ -704,8 +717,24 @@ extern "C" size_t stof_hilbert_workspace_bytes(int64_t N, int64_t n) {
     return bytes;
 }
 
+namespace {
+int hilbert_impl(const float* x, int64_t N, int64_t n, float* env, float* re, float* im, void* workspace, size_t workspace_bytes,
+                 void* stream_, int streamed);
+}
+
 extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, float* re, float* im,
-                            void* workspace, size_t workspace_bytes, void* stream_) {
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    return hilbert_impl(x, N, n, env, re, im, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int stof_hilbert_streamed(const float* x, int64_t N, int64_t n, float* env, float* re, float* im,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    return hilbert_impl(x, N, n, env, re, im, workspace, workspace_bytes, stream, 1);
+}
+
+namespace {
+int hilbert_impl(const float* x, int64_t N, int64_t n, float* env, float* re, float* im, void* workspace, size_t workspace_bytes,
+                 void* stream_, int streamed) {
     if (N < 0 || n < 0) return STOF_ERR_BAD_ARG;
     if (N == 0 || n == 0) return STOF_OK;
     if (!x || (!env && !re && !im)) return STOF_ERR_BAD_ARG;
@@ -715,7 +744,7 @@ extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, fl
     const int ncu = stof::device_cu_count();
 
     {
-        const int st = try_launch_ct(x, N, n, env, re, im, ncu, stream);
+        const int st = try_launch_ct(x, N, n, env, re, im, ncu, stream, streamed);
         if (st >= 0) return st;
     }
     stof_fft::Plan fplan;
@@ -780,3 +809,4 @@ extern "C" int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, fl
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, x, tw, hf, plan, (long long)N, env, re, im, scratch);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
+}  // namespace

@@ -64,7 +64,7 @@ def _detect(frame_or_env, is_frame, grad_step, threshold, ival, echo_max, group=
     blurred = None
     with torch.cuda.device(x.device):
         if not fused:
-            env = hilbert_envelope(x) if is_frame else x
+            env = hilbert_envelope(x, keep_cached=True) if is_frame else x
             if threshold is None:
                 # Q7: (unbiased std of the WHOLE batch tensor) ** 16 * 1.2e13 (models/gradpeak.py:18), formed on the device
                 stats = torch.tensor([0.0, 0.0, float(n * L)], dtype=torch.float64, device=x.device)

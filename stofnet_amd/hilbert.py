@@ -6,7 +6,7 @@ import torch.nn as nn
 from . import _lib
 
 
-def _run(y: torch.Tensor, want_env: bool, want_complex: bool):
+def _run(y: torch.Tensor, want_env: bool, want_complex: bool, keep_cached: bool = False):
     _lib.require_device(y, 'y')
     n = y.shape[-1]
     rows = y.numel() // max(n, 1)
@@ -17,8 +17,9 @@ def _run(y: torch.Tensor, want_env: bool, want_complex: bool):
     re = torch.empty_like(yc) if want_complex else None
     im = torch.empty_like(yc) if want_complex else None
     with torch.cuda.device(y.device):
-        _lib.check(lib.stof_hilbert(_lib.ptr(yc), rows, n, _lib.ptr(env), _lib.ptr(re), _lib.ptr(im),
-                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(y.device)), 'stof_hilbert')
+        call = lib.stof_hilbert if keep_cached else lib.stof_hilbert_streamed
+        _lib.check(call(_lib.ptr(yc), rows, n, _lib.ptr(env), _lib.ptr(re), _lib.ptr(im),
+                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr(y.device)), 'stof_hilbert')
     return env, re, im
 
 
@@ -28,9 +29,10 @@ def hilbert_transform(y):
     return torch.complex(re, im).reshape(y.shape)
 
 
-def hilbert_envelope(y):
-    """abs(hilbert_transform(y)) without materialising the complex signal."""
-    env, _, _ = _run(y, True, False)
+def hilbert_envelope(y, keep_cached=False):
+    """abs(hilbert_transform(y)) without materialising the complex signal.  keep_cached: a kernel of this package reads
+    the envelope next (GradPeak); otherwise it is written with non-temporal stores (stof_hilbert_streamed)."""
+    env, _, _ = _run(y, True, False, keep_cached)
     return env.reshape(y.shape)
 
 
