@@ -286,6 +286,7 @@ __global__ __launch_bounds__(512) void hilbert_generic_kernel(const float* __res
 // PAIR un-mixing (even n): z = x1 + i x2, ifft(H fft(z)) = a1 + i a2 with a_j = x_j + i v_j the analytic signals,
 // so Re = x1 - v2, Im = v1 + x2, hence v1 = Im - x2, v2 = x1 - Re.
 // ----------------------------------------------------------------------------------------------------------------
+template <bool NT>      // NT: envelope written with non-temporal stores (stof_hilbert_streamed)
 __global__ __launch_bounds__(512) void hilbert_pairs_kernel(const float* __restrict__ x, const stof_fft::Plan plan,
                                                             long long nrows, float* __restrict__ env,
                                                             float* __restrict__ re, float* __restrict__ im) {
@@ -321,11 +322,16 @@ __global__ __launch_bounds__(512) void hilbert_pairs_kernel(const float* __restr
             [&](int q, const float (&xa)[4], const float (&v1)[4], const float (&xb)[4], const float (&v2)[4]) {
                 using stof_io::envelope;
                 if (e1) {
-                    *reinterpret_cast<float4*>(e1 + 4 * q) = make_float4(envelope(xa[0], v1[0]), envelope(xa[1], v1[1]),
-                                                                         envelope(xa[2], v1[2]), envelope(xa[3], v1[3]));
-                    if (second)
-                        *reinterpret_cast<float4*>(e1 + n + 4 * q) = make_float4(envelope(xb[0], v2[0]), envelope(xb[1], v2[1]),
-                                                                                 envelope(xb[2], v2[2]), envelope(xb[3], v2[3]));
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f ea = {envelope(xa[0], v1[0]), envelope(xa[1], v1[1]), envelope(xa[2], v1[2]), envelope(xa[3], v1[3])};
+                    const v4f eb = {envelope(xb[0], v2[0]), envelope(xb[1], v2[1]), envelope(xb[2], v2[2]), envelope(xb[3], v2[3])};
+                    if constexpr (NT) {
+                        __builtin_nontemporal_store(ea, reinterpret_cast<v4f*>(e1 + 4 * q));
+                        if (second) __builtin_nontemporal_store(eb, reinterpret_cast<v4f*>(e1 + n + 4 * q));
+                    } else {
+                        *reinterpret_cast<v4f*>(e1 + 4 * q) = ea;
+                        if (second) *reinterpret_cast<v4f*>(e1 + n + 4 * q) = eb;
+                    }
                 }
                 if (r1) {
                     *reinterpret_cast<float4*>(r1 + 4 * q) = make_float4(xa[0], xa[1], xa[2], xa[3]);
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(256) void outer_forward_kernel(const float* __restr
     }
 }
 
-template <int R0>
+template <int R0, bool NT>
 __global__ __launch_bounds__(256) void outer_inverse_kernel(const float* __restrict__ x, long long nrows, long long pair0, int M,
                                                             const float2* __restrict__ twn, const float2* __restrict__ scratch,
                                                             float* __restrict__ env, float* __restrict__ re, float* __restrict__ im) {
@@ -563,7 +569,16 @@ __global__ __launch_bounds__(256) void outer_inverse_kernel(const float* __restr
         const size_t i = j + (size_t)M * k;
         const float a = x1[i], b = x2 ? x2[i] : 0.f;
         const float v1 = z.y - b, v2 = a - z.x;                   // pair un-mixing (see hilbert_pairs_kernel)
-        if (env) { env[row * n + i] = stof_io::envelope(a, v1); if (second) env[(row + 1) * n + i] = stof_io::envelope(b, v2); }
+        if (env) {
+            const float ea = stof_io::envelope(a, v1), eb = stof_io::envelope(b, v2);
+            if constexpr (NT) {
+                __builtin_nontemporal_store(ea, env + row * n + i);
+                if (second) __builtin_nontemporal_store(eb, env + (row + 1) * n + i);
+            } else {
+                env[row * n + i] = ea;
+                if (second) env[(row + 1) * n + i] = eb;
+            }
+        }
         if (re) { re[row * n + i] = a; if (second) re[(row + 1) * n + i] = b; }
         if (im) { im[row * n + i] = v1; if (second) im[(row + 1) * n + i] = v2; }
     }
@@ -636,10 +651,13 @@ int launch_blocks(float2* blocks, int64_t nblocks, int R0, float inv_n, int ncu,
 
 template <int R0>
 void launch_outer(bool inverse, const float* x, int64_t nrows, int64_t pair0, int64_t npairs, int M, const float2* twn,
-                  float2* scratch, float* env, float* re, float* im, hipStream_t stream) {
+                  float2* scratch, float* env, float* re, float* im, hipStream_t stream, int streamed) {
     const dim3 grid((unsigned)((M + 255) / 256), (unsigned)npairs);
-    if (inverse)
-        hipLaunchKernelGGL(outer_inverse_kernel<R0>, grid, dim3(256), 0, stream, x, (long long)nrows, (long long)pair0, M, twn,
+    if (inverse && streamed)
+        hipLaunchKernelGGL((outer_inverse_kernel<R0, true>), grid, dim3(256), 0, stream, x, (long long)nrows, (long long)pair0, M, twn,
+                           (const float2*)scratch, env, re, im);
+    else if (inverse)
+        hipLaunchKernelGGL((outer_inverse_kernel<R0, false>), grid, dim3(256), 0, stream, x, (long long)nrows, (long long)pair0, M, twn,
                            (const float2*)scratch, env, re, im);
     else
         hipLaunchKernelGGL(outer_forward_kernel<R0>, grid, dim3(256), 0, stream, x, (long long)nrows, (long long)pair0, M, twn, scratch);
@@ -647,7 +665,7 @@ void launch_outer(bool inverse, const float* x, int64_t nrows, int64_t pair0, in
 
 // the workspace holds w_n^j (j < M) followed by the scratch of one chunk of pairs
 int run_four_step(const FourStepPlan& fp, const float* x, int64_t nrows, int64_t n, float* env, float* re, float* im,
-                  void* workspace, int ncu, hipStream_t stream) {
+                  void* workspace, int ncu, hipStream_t stream, int streamed) {
     float2* twn = static_cast<float2*>(workspace);
     float2* scratch = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + ((size_t)fp.M * sizeof(float2) + 255) / 256 * 256);
     hipLaunchKernelGGL(outer_table_kernel, dim3((unsigned)((fp.M + 255) / 256)), dim3(256), 0, stream, twn, fp.M, (int)n);
@@ -670,12 +688,12 @@ int run_four_step(const FourStepPlan& fp, const float* x, int64_t nrows, int64_t
             }
             const bool inv = pass == 2;
             switch (fp.R0) {
-                case 6: launch_outer<6>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
-                case 8: launch_outer<8>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
-                case 10: launch_outer<10>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
-                case 15: launch_outer<15>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
-                case 16: launch_outer<16>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
-                default: launch_outer<20>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream); break;
+                case 6: launch_outer<6>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream, streamed); break;
+                case 8: launch_outer<8>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream, streamed); break;
+                case 10: launch_outer<10>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream, streamed); break;
+                case 15: launch_outer<15>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream, streamed); break;
+                case 16: launch_outer<16>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream, streamed); break;
+                default: launch_outer<20>(inv, x, nrows, p0, np, fp.M, twn, scratch, env, re, im, stream, streamed); break;
             }
         }
     }
@@ -750,7 +768,9 @@ int hilbert_impl(const float* x, int64_t N, int64_t n, float* env, float* re, fl
     stof_fft::Plan fplan;
     if (const size_t flds = stof::hilbert_fast_lds_bytes(n, &fplan)) {
         static stof::LdsLimitOnce fast_once;
-        if (int st = fast_once.ensure(reinterpret_cast<const void*>(&hilbert_pairs_kernel), LDS_BYTES)) return st;
+        if (int st = fast_once.ensure(reinterpret_cast<const void*>(&hilbert_pairs_kernel<false>), LDS_BYTES)) return st;
+        static stof::LdsLimitOnce fast_once_nt;
+        if (int st = fast_once_nt.ensure(reinterpret_cast<const void*>(&hilbert_pairs_kernel<true>), LDS_BYTES)) return st;
         // threads per pair: enough waves per CU to hide LDS latency whatever the row length
         int per_cu = (int)((size_t)LDS_BYTES / flds);
         if (per_cu > 16) per_cu = 16;
@@ -760,7 +780,11 @@ int hilbert_impl(const float* x, int64_t N, int64_t n, float* env, float* re, fl
         const int64_t npairs = (N + 1) / 2;
         int64_t grid = (int64_t)ncu * per_cu;
         if (grid > npairs) grid = npairs;
-        hipLaunchKernelGGL(hilbert_pairs_kernel, dim3((unsigned)grid), dim3(threads), flds, stream, x, fplan, (long long)N,
+        if (streamed)
+            hipLaunchKernelGGL(hilbert_pairs_kernel<true>, dim3((unsigned)grid), dim3(threads), flds, stream, x, fplan, (long long)N,
+                           env, re, im);
+        else
+            hipLaunchKernelGGL(hilbert_pairs_kernel<false>, dim3((unsigned)grid), dim3(threads), flds, stream, x, fplan, (long long)N,
                            env, re, im);
         return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
     }
@@ -772,7 +796,7 @@ int hilbert_impl(const float* x, int64_t N, int64_t n, float* env, float* re, fl
         for (const void* p : {(const void*)x, (const void*)env, (const void*)re, (const void*)im, (const void*)workspace})
             aligned = aligned && !(reinterpret_cast<size_t>(p) & 15);
         if (fs_mode && aligned && n % 2 == 0 && four_step_plan(n, &fsp))
-            return run_four_step(fsp, x, N, n, env, re, im, workspace, ncu, stream);
+            return run_four_step(fsp, x, N, n, env, re, im, workspace, ncu, stream, streamed);
     }
     FftPlan plan;
     make_plan((int)n, &plan);
