@@ -81,23 +81,79 @@ def free_port():
         return s.getsockname()[1]
 
 
+def _tail(path, n=30):
+    try:
+        with open(path, 'rb') as f:
+            return b''.join(f.readlines()[-n:]).decode(errors='replace')
+    except OSError:
+        return ''
+
+
+def _stop(procs, grace=5.0):
+    """End exactly the children this launcher started (by PID): SIGTERM, then SIGKILL after `grace` seconds."""
+    live = [p for p in procs if p.poll() is None]
+    for p in live:
+        p.terminate()
+    t_end = time.monotonic() + grace
+    for p in live:
+        try:
+            p.wait(max(0.0, t_end - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+
+
 def launch_children(args, argv):
+    """One child per GPU; all of them are polled.  The first non-zero exit (or the watchdog) ends the siblings at once
+    and the launcher returns non-zero with the failing rank's stderr tail: a dead rank cannot leave rank 0 waiting in
+    RCCL init / a barrier until the process-group timeout.  Per-rank stderr goes to <logdir>/bench_rank<r>.err."""
     port = os.environ.get('MASTER_PORT') or str(free_port())
-    procs = []
+    logdir = os.environ.get('STOF_BENCH_LOGDIR') or os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(logdir, exist_ok=True)
+    limit = float(os.environ.get('STOF_BENCH_TIMEOUT', '540'))
+    procs, errs, files = [], [], []
+    out0_path = os.path.join(logdir, f'bench_rank0.{os.getpid()}.out')
     for rank in range(args.gpus):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        err_path = os.path.join(logdir, f'bench_rank{rank}.err')
+        ferr = open(err_path, 'wb')
+        fout = open(out0_path, 'wb') if rank == 0 else subprocess.DEVNULL
+        files += [ferr] + ([fout] if rank == 0 else [])
+        errs.append(err_path)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+                                      stdout=fout, stderr=ferr))
+    t0 = time.monotonic()
+    verdict = None
+    while verdict is None:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            verdict = f'ranks failed (rank, exit code): {bad}'
+        elif all(c == 0 for c in codes):
+            verdict = ''
+        elif time.monotonic() - t0 > limit:
+            verdict = f'watchdog: no result after {limit:.0f} s; still running: {[r for r, c in enumerate(codes) if c is None]}'
+        else:
+            time.sleep(0.1)
+    _stop(procs)
+    for f in files:
+        f.close()
+    sys.stdout.write(open(out0_path).read())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.stderr.write(f'bench.py: ranks failed (rank, exit code): {bad}\n')
+    try:
+        os.remove(out0_path)
+    except OSError:
+        pass
+    if verdict:
+        sys.stderr.write(f'bench.py: {verdict}\n')
+        first = bad[0][0] if bad else 0
+        sys.stderr.write(f'---- stderr tail of rank {first} ({errs[first]}) ----\n{_tail(errs[first])}\n')
         return 1
+    for r, path in enumerate(errs):            # relay rank 0's warnings; keep the other ranks' files for inspection
+        if r == 0:
+            sys.stderr.write(_tail(path, 10))
     return 0
 
 
@@ -196,22 +252,66 @@ class Dist:
             raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: launch with '
                              f'`python bench.py --gpus N` or torch.distributed.run --nproc-per-node N')
         self.dist = None
-        if getattr(args, 'rehearse_on_one_gpu', False) and backend == 'nccl':
+        self.rehearsal = bool(getattr(args, 'rehearse_on_one_gpu', False)) and backend == 'nccl'
+        if self.rehearsal:
             backend, self.local_rank = 'gloo-gpu', 0
+        self.backend = backend
         self.dev = torch.device('cpu') if backend == 'gloo' else torch.device('cuda', self.local_rank)
+        fail_rank = os.environ.get('STOF_TEST_FAIL_RANK')          # tests/test_bench_launcher.py: one rank dies before init
+        if fail_rank is not None and int(fail_rank) == self.rank:
+            sys.stderr.write(f'bench.py: rank {self.rank} exits 3 on purpose (STOF_TEST_FAIL_RANK)\n')
+            sys.stderr.flush()
+            os._exit(3)
+        if os.environ.get('STOF_TEST_HANG_RANK') is not None and int(os.environ['STOF_TEST_HANG_RANK']) == self.rank:
+            time.sleep(3600)                                       # tests: the launcher's watchdog must end this
+        if backend == 'nccl' and torch.cuda.device_count() < max(self.world, self.local_rank + 1):
+            raise SystemExit(f'bench.py: rank {self.rank} sees {torch.cuda.device_count()} GPU(s) but WORLD_SIZE={self.world} '
+                             f'(one process per GPU): refusing to start')
         if self.world > 1:
+            import datetime
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            tmo = datetime.timedelta(seconds=float(os.environ.get('STOF_DIST_TIMEOUT', '180')))
             if backend == 'nccl':
                 torch.cuda.set_device(self.local_rank)
-                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.dev)
+                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.dev, timeout=tmo)
             else:
-                dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
+                dist.init_process_group('gloo', rank=self.rank, world_size=self.world, timeout=tmo)
             self.dist = dist
         if backend != 'gloo':
             torch.cuda.set_device(self.dev)
+
+    def census(self):
+        """Proof in the record that `world` distinct devices took part: ranks_seen = SUM all-reduce of ones, and the
+        gathered identity (uuid / PCI bus id / name) of every rank's device.  Rehearsal runs say so in the line."""
+        import torch
+        ident = {'rank': self.rank, 'device': str(self.dev)}
+        if self.dev.type == 'cuda':
+            pr = torch.cuda.get_device_properties(self.dev)
+            ident['name'] = pr.name
+            for key in ('uuid', 'pci_bus_id', 'pci_device_id', 'pci_domain_id'):
+                if hasattr(pr, key):
+                    ident[key] = str(getattr(pr, key))
+        seen, idents = 1, [ident]
+        if self.dist is not None:
+            one = torch.ones(1, dtype=torch.int32, device=self.dev)
+            self.dist.all_reduce(one, op=self.dist.ReduceOp.SUM)
+            seen = int(one.item())
+            idents = [None] * self.world
+            self.dist.all_gather_object(idents, ident)
+        keys = {(i.get('uuid'), i.get('pci_domain_id'), i.get('pci_bus_id'), i.get('pci_device_id'))
+                if (i.get('uuid') or i.get('pci_bus_id')) else i['device'] for i in idents}
+        physical = 1 if (self.rehearsal or self.dev.type != 'cuda') else len(keys)
+        out = {'ranks_seen': seen, 'physical_gpus': physical if self.dev.type == 'cuda' else 0,
+               'collective_backend': {'nccl': 'nccl (RCCL)', 'gloo-gpu': 'gloo (one-GPU rehearsal)', 'gloo': 'gloo (CPU dry run)'}[self.backend],
+               'devices': idents}
+        if self.rehearsal:
+            out['rehearsal_on_one_gpu'] = True
+        if self.dev.type == 'cuda' and not self.rehearsal and physical != self.world:
+            out['warning'] = f'{self.world} ranks but {physical} distinct device identities'      # reported, not fatal
+        return out
 
     def barrier(self):
         if self.dist is not None:
@@ -270,10 +370,12 @@ def dry_run(args):
         counts_all, idx_all = gather_onsets(counts, idx)
         gather_ms = (time.perf_counter() - t1) * 1e3
         assert counts_all.shape[0] == rows * d.world and idx_all.shape[1] == d.world
+    census = d.census()
     if d.rank == 0:
         out = base_line(args, d, 'dry run (no kernels)', d.world * rows * args.steps / dt, dt, 'none',
                         'launcher rehearsal on CPU/gloo', {'rows_per_gpu': rows})
         out['dry_run'] = True
+        out['ranks'] = census
         out['extras'] = {'index_gather_ms': None if gather_ms is None else round(gather_ms, 3)}
         print(json.dumps(out), flush=True)
     d.finish()
@@ -304,6 +406,7 @@ def train_bench(args):
     for s in range(args.warmup):
         step(s)
     dt = d.timed(step, args.steps)
+    census = d.census()
     if d.rank == 0:
         flops = 3.0 * total_flops(nb, L, R)        # forward + data-gradient + weight-gradient
         achieved = flops * args.steps / dt / 1e12
@@ -317,7 +420,8 @@ def train_bench(args):
                            'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                            'frac': round(achieved / peak, 4), 'traffic': None}
         out['final_loss'] = float(last['loss'])
-        if d.world == 1 and not args.no_cpu_baseline:
+        out['ranks'] = census
+        if not args.no_cpu_baseline:       # rank 0 only; at N > 1 the other ranks wait in finish()'s barrier meanwhile
             # the oracle's training step (torch autograd on the host cores), bounded sample
             from oracle import train_oracle
             cores = host_cores()
@@ -467,18 +571,33 @@ def infer_bench(args):
         def fused_pass():
             for c in range(nchunk):
                 model.forward_onsets(x if nchunk == 1 else x[c * chunk:(c + 1) * chunk], 20)
+        def fused_stream():      # serving form: no host read per call; counts / guard word are read after the loop
+            for c in range(nchunk):
+                res['fused'] = model.forward_onsets(x if nchunk == 1 else x[c * chunk:(c + 1) * chunk], 20, sync=False)
         fused_pass()
+        fused_stream()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(3):
             fused_pass()
         torch.cuda.synchronize()
         fdt = (time.perf_counter() - t1) / 3
+        t1 = time.perf_counter()
+        for _ in range(5):
+            fused_stream()
+        torch.cuda.synchronize()
+        fdt_ns = (time.perf_counter() - t1) / 5
+        kmax_ns = int(res['fused'][0].max())
         fc, fi = model.forward_onsets(x[:chunk], 20)
         rc, ri = onset_indices(model(x[:chunk]), 20, None)
-        extras['fused_argmax_onsets'] = {'ms_per_step': round(fdt * 1e3, 3), 'waveforms_per_s': round(d.world * rows / fdt, 1),
+        extras['fused_argmax_onsets'] = {'ms_per_step': round(fdt_ns * 1e3, 3), 'waveforms_per_s': round(d.world * rows / fdt_ns, 1),
+                                         'ms_per_step_with_host_sync': round(fdt * 1e3, 3),
+                                         'waveforms_per_s_with_host_sync': round(d.world * rows / fdt, 1),
+                                         'kmax_read_after_loop': kmax_ns,
                                          'identical_to_map_plus_picker': bool(torch.equal(fc, rc) and torch.equal(fi, ri)),
-                                         'note': 'StofNet.forward_onsets: output = onset indices only (includes the Kmax host sync)'}
+                                         'note': 'StofNet.forward_onsets(sync=False): output = onset indices only, counts and the '
+                                                 'range-guard word read once after the timed loop; the *_with_host_sync figures '
+                                                 'include the per-call Kmax read the reference has (utils/mask2samples.py:93)'}
     extras['index_gather_ms'] = None
     if d.dist is not None:
         gather_onsets(counts, idx)                       # warm-up (communicator set-up)
@@ -509,19 +628,25 @@ def infer_bench(args):
                                      'onset_index_mismatches_vs_timed_mode': int((i32[:, :1] != idx[:, :1]).sum())}
         del m32, y32
     extras['auto_mode_fp32_rerun_taken'] = bool(fell_back)
+    census = d.census()
 
     if d.rank == 0:
         launch_rows = min(chunk, 4096)              # stof_forward sweeps sub-batches of <= 4096 rows per launch
         body_s = k_ms[2] * 1e-3
         achieved = body_flops(launch_rows, L, R) / body_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        traffic = None
+        # HBM bytes per launch cannot be read inside this process (rocprofv3 PMC passes run the whole command under the
+        # profiler, tools/profile_bench.sh): the figure is the committed record of such a pass and is labelled as one
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-        if os.path.exists(tpath) and cfg == 'C2':
+        if os.path.exists(tpath) and cfg == 'C2' and rows == 4096 and args.precision != 'fp32':
             try:
-                traffic = json.load(open(tpath)).get('body_sweep_hbm_bytes_per_launch')
+                rec = json.load(open(tpath))
+                traffic = rec.get('body_sweep_hbm_bytes_per_launch')
+                traffic_source = (f"NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, "
+                                  f"profiles/traffic_latest.json <- {rec.get('source')}; recorded {rec.get('date', 'round 2')}")
             except Exception:  # noqa: BLE001
-                traffic = None
+                traffic, traffic_source = None, None
         metric = 'RF waveforms/sec StofNet inference rf_scale=10'
         if cfg == 'C3':
             metric = 'RF waveforms/sec StofNet inference rf_scale=20'
@@ -533,13 +658,14 @@ def infer_bench(args):
         out['preheat_steps'] = preheat
         out['roofline'] = {'bound': 'mfma', 'kernel': 'body_sweep_kernel', 'achieved': round(achieved, 2),
                            'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
-                           'flops_per_launch': body_flops(launch_rows, L, R), 'avg_launch_ms': round(float(k_ms[2]), 4),
+                           'traffic_source': traffic_source, 'flops_per_launch': body_flops(launch_rows, L, R), 'avg_launch_ms': round(float(k_ms[2]), 4),
                            'rows_per_launch': launch_rows}
         out['kernels_ms'] = {'sgb_contract_pool': round(float(k_ms[0]), 4), 'sgb_expand': round(float(k_ms[1]), 4),
                              'body_sweep': round(float(k_ms[2]), 4)}
         out['whole_forward_tflops'] = round(total_flops(rows, L, R) * d.world * args.steps / dt / 1e12, 2)
         out['extras'] = extras
-        if d.world == 1 and not args.no_cpu_baseline:
+        out['ranks'] = census
+        if not args.no_cpu_baseline:       # rank 0 only; at N > 1 the other ranks wait in finish()'s barrier meanwhile
             srows = 256 if cfg != 'C4' else 128
             xs = x[:srows].cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(sd, R, L, xs, y[:srows] if cfg != 'C4' else model(x[:srows]),

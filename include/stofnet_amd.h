@@ -189,7 +189,8 @@ int stof_hilbert_streamed(const float* x, int64_t N, int64_t n, float* env, floa
  *   echoes[N, cap, 3], counts[N]        : (onset, peak, env[peak]) of the first `cap` echoes of each row, exact counts
  *   echo_max, reduced[N, echo_max, 3]   : echo_max > 0 also writes toa_detect's reduction (:107-114: echo_max largest
  *                                         amplitudes, then ascending time, the reference's zero padding taking part);
- *                                         the caller uses it iff flags[1] > echo_max
+ *                                         the caller uses it iff flags[1] > echo_max; echo_max > 0 with cap > 4096
+ *                                         returns STOF_ERR_UNSUPPORTED (the reduction ranks <= 4096 entries per row)
  *   flags[2] (zeroed by the call)       : flags[0] = 1 if some row has edges but no surviving candidate (Q9: the
  *                                         reference then returns an empty tensor for the batch), flags[1] = max(counts)
  * Nothing synchronises with the host; one read of `flags` after the call tells the caller what to slice.

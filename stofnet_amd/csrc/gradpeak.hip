@@ -116,7 +116,11 @@ __host__ __device__ inline int split_flag_offset(int radius) {   // floats befor
     return f + (f & 1);
 }
 inline size_t split_lds_bytes(int L, int radius, int W) {
-    return (size_t)split_flag_offset(radius) * 4 + (size_t)(4 / W) * 3 * stof_gp::word_count(L, radius) * 8;
+    // flag words of the rows of one work-group; the MOMENTS variant reuses the region for 8 doubles (64 B), which a
+    // short row (W = 4, two words: 48 B) would not cover
+    size_t flag_bytes = (size_t)(4 / W) * 3 * stof_gp::word_count(L, radius) * 8;
+    if (flag_bytes < 64) flag_bytes = 64;
+    return (size_t)split_flag_offset(radius) * 4 + flag_bytes;
 }
 
 template <bool MOMENTS>
@@ -487,6 +491,7 @@ extern "C" int stof_grad_peak_detect(const float* env, int64_t N, int64_t L, int
     if (!env || !taps || !counts || !flags || (!echoes && cap > 0) || bad_common(N, L, grad_step, radius, cap))
         return STOF_ERR_BAD_ARG;
     if (echo_max > 0 && !reduced) return STOF_ERR_BAD_ARG;
+    if (echo_max > 0 && cap > 4096) return STOF_ERR_UNSUPPORTED;      // reduce_row selects among <= 64 x 64 entries per row
     if (N == 0) return STOF_OK;
     if (radius > stof_gp::MAXRAD || L > 0x3fffffffLL || N > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
     const Config cf = make_config(L, grad_step, radius, threshold, ival_min, ival_max, cap, echo_max);
@@ -511,6 +516,7 @@ extern "C" int stof_grad_peak_detect_blurred(const float* env, const float* blur
                                              int32_t* flags, void* stream) {
     if (!env || !blurred || !counts || !flags || (!echoes && cap > 0) || bad_common(N, L, 1, radius, cap)) return STOF_ERR_BAD_ARG;
     if (echo_max > 0 && !reduced) return STOF_ERR_BAD_ARG;
+    if (echo_max > 0 && cap > 4096) return STOF_ERR_UNSUPPORTED;      // reduce_row selects among <= 64 x 64 entries per row
     if (N == 0) return STOF_OK;
     if (radius > stof_gp::MAXRAD || L > 0x3fffffffLL || N > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
     const Config cf = make_config(L, 1, radius, threshold, ival_min, ival_max, cap, echo_max);
@@ -533,6 +539,7 @@ extern "C" int stof_toa_detect(const float* frame, int64_t N, int64_t L, int32_t
     if (!frame || !taps || !counts || !flags || (!echoes && cap > 0) || bad_common(N, L, grad_step, radius, cap))
         return STOF_ERR_BAD_ARG;
     if (echo_max > 0 && !reduced) return STOF_ERR_BAD_ARG;
+    if (echo_max > 0 && cap > 4096) return STOF_ERR_UNSUPPORTED;      // reduce_row selects among <= 64 x 64 entries per row
     if (N == 0) return STOF_OK;
     if (N > 0x7fffffffLL || radius > stof_gp::MAXRAD) return STOF_ERR_UNSUPPORTED;
     FusedParams p;

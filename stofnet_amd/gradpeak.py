@@ -38,11 +38,20 @@ def _taps_on(device, grad_step):
 
 
 def _moment_reduce(stats, group):
-    """Q7 across ranks: the default threshold is the std of the WHOLE batch (models/gradpeak.py:18), so a sharded
-    batch sums its three moments (sum, sum of squares, count) over the ranks before the threshold is formed."""
+    """Q7 across ranks, OPT-IN: the default threshold is the std of the WHOLE batch (models/gradpeak.py:18), so a batch
+    whose rows are sharded over ranks sums its three moments (sum, sum of squares, count) over `group` before the
+    threshold is formed.  The reference has no collective here, so nothing is reduced unless the caller says the batch
+    is sharded (`group=` a process group, or `sharded=True` for the default group): a rank that calls GradPeak alone,
+    or ranks that all hold the SAME unsharded rows (main.evaluate under torchrun), keep local moments like the
+    reference.  With the reduction on, every rank of the group must make the same sequence of calls (lock-step)."""
+    if group is None:
+        return stats
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError('GradPeak: a sharded batch (group= / sharded=True) needs an initialised torch.distributed')
+    pg = None if group is True else group
+    if dist.get_world_size(pg) > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=pg)
     return stats
 
 
@@ -119,31 +128,35 @@ def _detect(frame_or_env, is_frame, grad_step, threshold, ival, echo_max, group=
 
 
 def grad_peak_detect(data, grad_step: int = None, threshold: float = None, ival_smin: int = None,
-                     ival_smax: int = None, group=None):
-    """models/gradpeak.py:8-68 -> [N, Kmax, 3] = (onset, peak, amplitude), zero padded.  `group`: process group of a
-    batch sharded over ranks (default group if torch.distributed is initialised)."""
+                     ival_smax: int = None, group=None, sharded=False):
+    """models/gradpeak.py:8-68 -> [N, Kmax, 3] = (onset, peak, amplitude), zero padded.  `group` / `sharded=True`:
+    the rows are one shard of a batch spread over that process group (default group) -- see _moment_reduce; by default
+    the moments behind the default threshold are local, as in the reference."""
     grad_step = grad_step if grad_step is not None else 2
     if ival_smin is not None and ival_smax is not None:
         ival = (int(ival_smin), int(ival_smax))
     else:
         ival = (grad_step // 2, grad_step * 3)
-    return _detect(data, False, grad_step, threshold, ival, None, group)
+    return _detect(data, False, grad_step, threshold, ival, None, group if group is not None else (True if sharded else None))
 
 
-def toa_detect(frame, threshold=None, rescale_factor=1, echo_max=float('inf'), group=None):
+def toa_detect(frame, threshold=None, rescale_factor=1, echo_max=float('inf'), group=None, sharded=False):
     """models/gradpeak.py:99-116: Hilbert envelope -> grad_peak_detect -> top-`echo_max` echoes by amplitude in time
     order.  With an explicit threshold and a row length the fused kernel supports this is ONE launch (stof_toa_detect);
     otherwise envelope kernel + (moments + threshold +) detection kernel.  Nothing here runs on ATen."""
     return _detect(frame, True, rescale_factor // 6 * 5, threshold, (int(rescale_factor), 50 * int(rescale_factor)),
-                   echo_max, group)
+                   echo_max, group if group is not None else (True if sharded else None))
 
 
 class GradPeak(torch.nn.Module):
-    def __init__(self, threshold=None, rescale_factor=1, echo_max=float('inf'), onset_opt=False):
+    def __init__(self, threshold=None, rescale_factor=1, echo_max=float('inf'), onset_opt=False, group=None, sharded=False):
+        """Reference signature (models/gradpeak.py:120) + `group` / `sharded` (new, default off): set when every rank
+        feeds a different shard of one batch and the default threshold must still be the whole batch's."""
         super().__init__()
         self.threshold = threshold
         self.onset_opt = onset_opt
-        self._fun = lambda x: toa_detect(x, threshold=threshold, rescale_factor=rescale_factor, echo_max=echo_max)
+        self._fun = lambda x: toa_detect(x, threshold=threshold, rescale_factor=rescale_factor, echo_max=echo_max,
+                                         group=group, sharded=sharded)
 
     def forward(self, x):
         echoes = self._fun(x.squeeze(1))

@@ -172,13 +172,17 @@ class StofNet(nn.Module):
         return y
 
     # ---- forward with the arg-max picker fused into the sweep ---------------------------------
-    def forward_onsets(self, x, window_size=20, return_map=False, cap=32):
+    def forward_onsets(self, x, window_size=20, return_map=False, cap=32, sync=True):
         """`model(x)` followed by `get_maxima_positions(., window_size, threshold=None)` (main.py:314 -> 320 with th=Null)
         in one pass: returns (counts[N] int32, idx[N, Kmax] int32) -- the integer onset sample indices of every row, ties
         and all, identical to `onset_indices(model(x), window_size)` -- and the map too if `return_map`.  Without the map
         the network output never touches HBM (4 bytes per onset instead of 4*L*r per waveform).  The picker lives in the
         split-fp16 sweep's 16-channel conv_last tile: for precision='fp32' or upsample_factor > 16 (and for an input
-        that overflows the fp16 range in 'auto' mode) this falls back to forward() + the picker kernel."""
+        that overflows the fp16 range in 'auto' mode) this falls back to forward() + the picker kernel.
+
+        sync=False (serving loops, bench.py): no host read at all -- returns (counts[N], idx[N, cap]) as launched; entries
+        beyond a row's count are undefined, a count above `cap` means the row's list is truncated, and the caller checks
+        `fell_back_to_fp32()` / counts once per many calls instead of once per call."""
         from .mask2samples import onset_indices
         _lib.require_device(x, 'x')
         if x.dim() != 3 or x.shape[1] != self.in_channels:
@@ -217,6 +221,8 @@ class StofNet(nn.Module):
             if code == _lib.STOF_ERR_ODD_SGB_REMAINDER or code == _lib.STOF_ERR_POOL_EMPTY:
                 return via_map()                                  # raises the reference's error
             _lib.check(code, 'stof_forward_onsets')
+            if not sync:
+                return (counts, idx, y) if return_map else (counts, idx)
             kmax = int(torch.maximum(counts.max(), self._status[0] * (cap + 1)))   # the reference's host sync (mask2samples.py:93)
             if int(self._status.item()):                          # an activation left the fp16 range
                 if self.precision == 'f16x3':

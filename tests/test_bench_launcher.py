@@ -53,3 +53,48 @@ def test_gpus_flag_must_agree_with_world_size():
 def test_failed_rank_gives_nonzero_exit():
     p = run(['--gpus', '2', '--steps', '1', '--dry-run', '--config', 'bogus'])
     assert p.returncode != 0
+
+
+def test_one_dead_rank_ends_the_run_quickly(tmp_path):
+    """Rank 1 dies before the rendezvous (STOF_TEST_FAIL_RANK): rank 0 would wait in init_process_group until the
+    process-group timeout; the launcher polls every child, ends the survivors and reports the dead rank."""
+    import time
+    t0 = time.monotonic()
+    p = run(['--gpus', '2', '--steps', '1', '--dry-run'], env={'STOF_TEST_FAIL_RANK': '1', 'STOF_BENCH_LOGDIR': str(tmp_path)},
+            timeout=120)
+    took = time.monotonic() - t0
+    assert p.returncode != 0
+    assert took < 30, f'launcher took {took:.1f} s to notice a dead rank'
+    assert '(1, 3)' in p.stderr and 'STOF_TEST_FAIL_RANK' in p.stderr         # which rank, which code, its stderr tail
+    assert json_lines(p.stdout) == []
+
+
+def test_watchdog_ends_a_hung_run(tmp_path):
+    p = run(['--gpus', '2', '--steps', '1', '--dry-run'], env={'STOF_TEST_HANG_RANK': '1', 'STOF_BENCH_TIMEOUT': '8',
+                                                                'STOF_BENCH_LOGDIR': str(tmp_path)}, timeout=120)
+    assert p.returncode != 0 and 'watchdog' in p.stderr
+
+
+def test_line_proves_the_ranks_that_took_part(tmp_path):
+    p = run(['--gpus', '2', '--steps', '2', '--warmup', '0', '--dry-run'], env={'STOF_BENCH_LOGDIR': str(tmp_path)})
+    assert p.returncode == 0, p.stderr[-2000:]
+    ranks = json_lines(p.stdout)[0]['ranks']
+    assert ranks['ranks_seen'] == 2 and [r['rank'] for r in ranks['devices']] == [0, 1]
+    assert ranks['physical_gpus'] == 0 and 'gloo' in ranks['collective_backend']      # a CPU dry run says so in the record
+
+
+def test_under_torch_distributed_run_like_the_driver(tmp_path):
+    """The driver's N > 1 launch line: torch.distributed.run provides RANK / WORLD_SIZE / MASTER_*."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, STOF_BENCH_LOGDIR=str(tmp_path))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), BENCH, '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--dry-run'], capture_output=True, text=True, env=e, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1 and lines[0]['n_gpus'] == 2 and lines[0]['ranks']['ranks_seen'] == 2

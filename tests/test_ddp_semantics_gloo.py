@@ -104,3 +104,27 @@ def test_blurred_target_uses_the_batch_global_maximum():
     gt = np.array([[[200, 202]], [[300, 302]], [[100, 400]], [[50, 500]]], np.int64)
     full_loss, full_grads, _ = to.loss_and_grads(sd, x, gt, r, 80)
     mp.spawn(_target_max_worker, args=(2, _free_port(), sd, x, gt, r, full_loss, full_grads), nprocs=2, join=True)
+
+
+def _moment_worker(rank, world, port):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from stofnet_amd.gradpeak import _moment_reduce
+        local = torch.tensor([1.0 + rank, 2.0 + rank, 100.0], dtype=torch.float64)
+        # default: local moments like the reference (models/gradpeak.py:18 has no collective); only rank 0 calls --
+        # with a hidden all-reduce this would deadlock, and unsharded rows on every rank would count W times
+        if rank == 0:
+            assert torch.equal(_moment_reduce(local.clone(), None), local)
+        dist.barrier()
+        # opt-in (sharded=True -> default group; or an explicit group): sum, sum of squares and count add up
+        got = _moment_reduce(local.clone(), True)
+        assert torch.equal(got, torch.tensor([3.0, 5.0, 200.0], dtype=torch.float64))
+        got = _moment_reduce(local.clone(), dist.group.WORLD)
+        assert torch.equal(got, torch.tensor([3.0, 5.0, 200.0], dtype=torch.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradpeak_moment_reduction_is_opt_in():
+    mp.spawn(_moment_worker, args=(2, _free_port()), nprocs=2, join=True)

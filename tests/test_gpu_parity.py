@@ -90,6 +90,36 @@ def test_forward_vs_fp64_truth(dev, case, wkey, r, sgs, precision):
     assert rel_err(y, truth) < MAP_TOL
 
 
+@pytest.mark.parametrize('precision', PRECISIONS + ['auto'])
+@pytest.mark.parametrize('scale', [1e-2, 1e-4, 1e-6])
+def test_forward_small_amplitude_inputs(dev, precision, scale):
+    """Un-normalised, small-amplitude inputs: the fp16 split hi = fp16(v), lo = fp16(v - hi) loses the lo
+    term's low bits to fp16 underflow for |v| < 2^-3, but the loss is ABSOLUTE (<= 2^-25 per operand, the half quantum
+    of an fp16 subnormal), i.e. below the fp32 rounding of any accumulator of magnitude >= 0.5 -- so maps and onset
+    indices of tiny inputs must still meet the fp32 bar against the float64 truth."""
+    g = golden('f1_armadillo_r4_L2000')
+    sd = load_weights('different-armadillo')
+    m = make_model(dev, sd, 4, 80, precision)
+    x = (g['x'][:4] * scale).astype(np.float32)
+    y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
+    truth = so.stofnet_forward(sd, x, 4, 80, torch.float64, conv=so.conv1d_shifted_matmul).numpy()
+    ref32 = so.stofnet_forward(sd, x, 4, 80).numpy()
+    err, err_ref = rel_err(y, truth), rel_err(ref32, truth)
+    assert err < MAP_TOL, f'scale {scale}: rel err {err:.3e} (torch fp32 itself: {err_ref:.3e})'
+    # the input-dependent part of the map (what a tiny input changes against a silent one), relative to ITS size
+    z = np.zeros_like(x)
+    y0 = m(torch.from_numpy(z).to(dev)).cpu().numpy()
+    t0 = so.stofnet_forward(sd, z, 4, 80, torch.float64, conv=so.conv1d_shifted_matmul).numpy()
+    r0 = so.stofnet_forward(sd, z, 4, 80).numpy()
+    resp_err = np.abs((y - y0) - (truth - t0)).max() / max(np.abs(truth - t0).max(), 1e-30)
+    resp_ref = np.abs((ref32 - r0) - (truth - t0)).max() / max(np.abs(truth - t0).max(), 1e-30)
+    print(f'small-amplitude scale {scale} {precision}: map err {err:.2e} (torch fp32 {err_ref:.2e}); '
+          f'response err {resp_err:.2e} (torch fp32 {resp_ref:.2e})')
+    if precision == 'fp32':
+        assert resp_err < max(4 * resp_ref, 1e-4), f'response err {resp_err:.3e} vs torch fp32 {resp_ref:.3e}'
+    assert np.array_equal(y[:, 0].argmax(-1), truth[:, 0].argmax(-1))
+
+
 @pytest.mark.parametrize('precision', PRECISIONS)
 def test_forward_seeded_r10(dev, precision):
     g = golden('f1_seeded_r10_L2000')

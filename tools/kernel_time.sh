@@ -1,7 +1,8 @@
 #!/bin/bash
 # kernel-only average durations (rocprofv3 --kernel-trace) of one tools/bench_aux.py case under a list of env settings
 #   bash tools/kernel_time.sh CASE "VAR=a VAR=b ..."       (each word is exported for one run)
-cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
+set -uo pipefail
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" && export TMPDIR=/tmp
 CASE=$1; shift
 for setting in "$@"; do
   export $setting

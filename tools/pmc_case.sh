@@ -1,6 +1,7 @@
 #!/bin/bash
 # Instruction-mix counters of one tools/bench_aux.py case:  bash tools/pmc_case.sh CASE [TAG]
-cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
+set -uo pipefail
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" && export TMPDIR=/tmp
 CASE=$1; TAG=${2:-x}
 OUT=gpurun_out/pmc_${CASE}_${TAG}
 rm -rf ${OUT}_1 ${OUT}_2

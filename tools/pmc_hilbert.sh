@@ -1,5 +1,6 @@
 # PMC passes over tools/prof_hilbert.py (Hilbert envelope + GradPeak kernels); summaries via tools/rocprof_summarize.py
-cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
+set -uo pipefail
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" && export TMPDIR=/tmp
 OUT=${1:-gpurun_out/r2_hil}
 for T in 64 128 256 512; do STOF_HILBERT_THREADS=$T python tools/bench_aux.py hilbert 2>/dev/null | sed "s/^/T=$T /"; done > ${OUT}_threads.txt
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d ${OUT}_pmc1 -- python3 tools/prof_hilbert.py > ${OUT}_pmc1.log 2>&1

@@ -1,5 +1,6 @@
 # PMC passes over the [4096,2000] Hilbert kernel only (ONLY=2000 tools/prof_hilbert.py); summary JSON on stdout
-cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp ONLY=2000 REPS=6
+set -uo pipefail
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" && export TMPDIR=/tmp ONLY=2000 REPS=6
 OUT=${1:-gpurun_out/r2_hilct}
 rm -rf ${OUT}_pmc*
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d ${OUT}_pmc1 -- python3 tools/prof_hilbert.py > ${OUT}_pmc1.log 2>&1

@@ -1,7 +1,8 @@
 #!/bin/bash
-# Bench lines of every config + rocprofv3 evidence for the default (C2) run; outputs under gpurun_out/r02_*
-cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
-O=gpurun_out/r02
+# Bench lines of every config + rocprofv3 evidence for the default (C2) run; outputs under gpurun_out/r03_*
+set -uo pipefail
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" && export TMPDIR=/tmp
+O=gpurun_out/r03
 python3 bench.py > ${O}_bench_c2.json 2> ${O}_bench_c2.err
 python3 bench.py --config C3 > ${O}_bench_c3.json 2> ${O}_bench_c3.err
 python3 bench.py --config C4 --steps 5 --warmup 1 > ${O}_bench_c4.json 2> ${O}_bench_c4.err
