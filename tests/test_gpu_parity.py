@@ -197,6 +197,29 @@ def test_argmax_indices_4096_rows_bit_exact(dev, precision):
     assert bad.size == 0, f'{bad.size} flips; min margin {margins.min():.3g}; margins at flips {margins[bad]}'
 
 
+@pytest.mark.parametrize('precision', PRECISIONS + ['auto'])
+def test_argmax_indices_4096_rows_at_the_benched_shape_r10(dev, precision):
+    """The benched configuration C2 ([4096,1,2000] -> [4096,1,20000], upsample_factor 10): arg-max onset indices of the
+    reference forward (different-armadillo body + the seeded conv_last of f1_armadillo_r10_L2000) for 4096 seeded echoes
+    (tests/golden/make_golden_r3.py argmax4096_r10), through the map + picker kernel AND through the picker fused into
+    the sweep (stof_forward_onsets)."""
+    from stofnet_amd.mask2samples import onset_indices
+    g = golden('f1_armadillo_r10_argmax4096')
+    sd = load_weights('different-armadillo')
+    sd['conv_last.weight'], sd['conv_last.bias'] = synth.synth_conv_last(10, seed=int(g['conv_last_seed']))
+    m = make_model(dev, sd, 10, precision=precision)
+    x = torch.from_numpy(synth.synth_echo(4096, 2000, seed=int(g['seed']))).to(dev)
+    counts, idx = onset_indices(m(x), 20, None)
+    margins = g['top2'][:, 0] - g['top2'][:, 1]
+    assert np.array_equal(counts.cpu().numpy(), np.ones(4096, np.int32)), 'a row has a tie the reference does not have'
+    got = idx[:, 0].cpu().numpy()
+    bad = np.nonzero(got != g['indices'])[0]
+    assert bad.size == 0, f'{bad.size} flips; min margin {margins.min():.3g}; margins at flips {margins[bad]}'
+    fc, fi = m.forward_onsets(x, 20)
+    assert torch.equal(fc, counts) and torch.equal(fi, idx)
+    print(f'r10 argmax 4096 rows {precision}: 0 flips, smallest top-2 margin {margins.min():.3g} (median {np.median(margins):.3g})')
+
+
 @pytest.mark.parametrize('precision', PRECISIONS)
 def test_forward_batch_and_workgroup_splits(dev, precision):
     """Rows are independent: any batch split gives identical bits (the sweep walks several
@@ -500,14 +523,6 @@ def test_gradpeak_degenerate_cases(dev):
         GradPeak(threshold=1e-2, rescale_factor=1)(torch.zeros(2, 1, 300, device=dev))
 
 
-def borderline_rows(frame, th, rf):
-    """Rows whose smoothed gradient (float64-pinned oracle) comes within rounding distance of a GradPeak threshold."""
-    sm = po.smoothed_gradient(po.hilbert_envelope(frame), rf // 6 * 5)
-    thr = np.float64(th) if th is not None else np.float64(po.default_threshold(sm))
-    eps = 2e-6 * np.abs(sm).max() + (0.0 if th is not None else 4e-5 * thr)      # Q7: rel. error of std x 16
-    return (np.minimum(np.abs(sm - thr), np.abs(sm + thr / 4)) <= eps).any(axis=1)
-
-
 @pytest.mark.parametrize('rf', [10, 20])
 @pytest.mark.parametrize('thn,th', [('1em3', 1e-3), ('none', None)])
 def test_gradpeak_1024_rows_exact_vs_reference(dev, rf, thn, th):
@@ -524,12 +539,10 @@ def test_gradpeak_1024_rows_exact_vs_reference(dev, rf, thn, th):
     idx, amp = g[f'idx_rf{rf}_th{thn}'], g[f'amp_rf{rf}_th{thn}']
     assert got.shape == idx.shape[:2] + (3,)
     differs = (got[..., :2] != idx).any(axis=(1, 2))
-    # A crossing is one comparison of a float the two FFTs round differently (and the default threshold is a 16th power
-    # of a batch statistic): a row may differ only if the float64 oracle puts one of its samples within rounding of a
-    # threshold, and only a handful of rows may.
-    borderline = borderline_rows(x.squeeze(1).cpu().numpy(), th, rf)
-    assert not (differs & ~borderline).any(), f'rows {np.nonzero(differs & ~borderline)[0][:8]} differ from the reference'
-    assert differs.sum() <= 2, f'{differs.sum()} of 1024 rows differ from the reference: rows {np.nonzero(differs)[0][:8]}'
+    # Measured (tools/gradpeak_exactness.py -> profiles/r03_gradpeak_exactness.json): 0 of 1024 rows differ in each of the
+    # four cases, and both the reference's fp32 and the kernels agree with the float64-exact pipeline on every row, so the
+    # bar is the north star's: integer indices bit-exact (r2 allowed 2 borderline rows without recording how many there were).
+    assert differs.sum() == 0, f'{differs.sum()} of 1024 rows differ from the reference: rows {np.nonzero(differs)[0][:8]}'
     same = ~differs
     assert np.abs(got[same, :, 2] - amp[same]).max() < ENV_TOL
     chirp = GradPeak(threshold=th, rescale_factor=rf, echo_max=1, onset_opt=True)(x).cpu().numpy()
@@ -554,7 +567,7 @@ def test_gradpeak_default_threshold_with_kept_blurred_gradient(dev, rf, monkeypa
     assert a.shape == b.shape and np.array_equal(a, b)
     idx = g[f'idx_rf{rf}_thnone']
     differs = (b[..., :2] != idx).any(axis=(1, 2))
-    assert differs.sum() <= 2 and not (differs & ~borderline_rows(x.cpu().numpy(), None, rf)).any()
+    assert differs.sum() == 0, f'rows {np.nonzero(differs)[0][:8]} differ from the reference'
     e3 = gp.GradPeak(threshold=None, rescale_factor=rf, echo_max=3, onset_opt=False)(x.unsqueeze(1)).cpu().numpy()
     assert np.array_equal(e3[~differs], g[f'em3_rf{rf}_thnone'][~differs])
 
@@ -667,6 +680,9 @@ def test_gradpeak_many_rows_margin_gated_exactness(dev):
     same = (pad(got)[..., :2] == pad(exp)[..., :2]).all(axis=(1, 2))
     assert same[clear].all(), f'{(~same[clear]).sum()} clear rows differ'
     print(f'borderline rows: {(~clear).sum()} of {n}, of which {(~same[~clear]).sum()} differ')
+    # measured: 288 borderline rows, none differs (profiles/r03_gradpeak_exactness.json: 0 of 4096 rows differ from the
+    # float64-exact pipeline either); a borderline row may still legitimately move on another input, so only report it
+    assert (~same).sum() <= 2
 
 
 def test_gradpeak_odd_batch_and_single_row(dev):
