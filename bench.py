@@ -57,6 +57,9 @@ def parse_args(argv=None):
     ap.add_argument('--train-batch', type=int, default=256, help='waveforms per GPU per training step')
     ap.add_argument('--train-precision', default='fp32', choices=['fp32', 'f16x3'],
                     help='arithmetic of the convolutions of the training step')
+    ap.add_argument('--trainer', default='fused', choices=['fused', 'autograd'],
+                    help="C5: 'fused' = StofNetTrainer (loss + AdamW kernels); 'autograd' = the reference's torch loss / "
+                         "torch.optim.AdamW lines on the module's autograd boundary (main.py:221-248)")
     ap.add_argument('--rows', type=int, default=0, help='override the rows per GPU of the chosen config (smoke runs)')
     ap.add_argument('--dry-run', action='store_true',
                     help='rehearse the launcher and the distributed plumbing on the CPU (gloo, no kernels): tests only')
@@ -393,7 +396,8 @@ def train_bench(args):
     sd = synth.synth_state_dict(R, seed=3008)
     model = StofNet(upsample_factor=R)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
-    tr = StofNetTrainer(model.to(d.dev), precision=args.train_precision)
+    model = model.to(d.dev)
+    tr = StofNetTrainer(model, precision=args.train_precision) if args.trainer == 'fused' else None
     nb = args.rows or args.train_batch
     x = torch.from_numpy(synth.synth_echo(nb, L, seed=3008 + d.rank)).to(d.dev)
     rng = np.random.default_rng(d.rank)
@@ -402,6 +406,29 @@ def train_bench(args):
 
     def step(_s):
         last['loss'], _ = tr.train_step(x, gt)
+
+    if args.trainer == 'autograd':
+        import torch.nn.functional as F
+        from stofnet_amd.mask2samples import coords2mask
+        from stofnet_amd.training import allreduce_max_, allreduce_mean_, gaussian_kernel
+        model.train_precision = args.train_precision
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-8)
+        gauss = torch.tensor(gaussian_kernel(7, 1.0), dtype=torch.float32, device=d.dev).unsqueeze(0).unsqueeze(0)
+        mse, l1 = torch.nn.MSELoss(reduction='mean'), torch.nn.L1Loss(reduction='mean')
+
+        def step(_s):      # noqa: F811  -- the reference's lines, main.py:221-248
+            pred = model(x)
+            blur = F.conv1d(coords2mask(gt.clone(), pred), gauss, padding=3)
+            blur = blur / allreduce_max_(blur.max().reshape(1)) * 20
+            loss = mse(pred.squeeze(1), blur.squeeze(1).float()) + l1(pred.squeeze(1), torch.zeros_like(pred.squeeze(1))) * 1e-2
+            opt.zero_grad()
+            loss.backward()
+            if d.world > 1:
+                for prm in model.parameters():
+                    allreduce_mean_(prm.grad)
+            opt.step()
+            last['loss'] = loss.detach()
 
     for s in range(args.warmup):
         step(s)
@@ -415,6 +442,7 @@ def train_bench(args):
                         d.world * nb * args.steps / dt, dt, DTYPE_TEXT[args.train_precision],
                         f'C5 training step [{nb},1,{L}] -> [{nb},1,{L * R}] per GPU, Gaussian-mask loss, AdamW, upsample_factor={R}',
                         {'rows_per_gpu': nb, 'L': L, 'upsample_factor': R, 'precision': args.train_precision,
+                         'trainer': args.trainer,
                          'parallelism': f'ddp{d.world}: one flat 2.58 MB gradient all-reduce per step'})
         out['roofline'] = {'bound': 'mfma', 'kernel': f'whole step (conv_cl_kernel + conv_wgrad kernels, {args.train_precision} MFMA)',
                            'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STOF_ABI_VERSION 2
+#define STOF_ABI_VERSION 3
 
 typedef enum stof_status {
     STOF_OK = 0,
@@ -285,15 +285,18 @@ size_t stof_train_conv1_wgrad_workspace_bytes(void);
 int stof_train_conv1_wgrad(const float* x, const float* g, const float* saved, float* dw, float* db,
                            int64_t N, int64_t L, float out_scale, void* workspace, size_t workspace_bytes,
                            void* stream);
-/* SemiGlobalBlock pieces (models/stofnet.py:103,108-115): MaxPool1d(80) with arg-max, its routing
- * backward (times lrelu' of the pre-pool activation), nearest upsample + pad + add and its backward. */
-int stof_train_pool(const float* c, float* pooled, uint8_t* arg, int64_t N, int64_t L, int64_t P, int32_t C, void* stream);
+/* SemiGlobalBlock pieces (models/stofnet.py:103,108-115), channel-last: MaxPool1d(scale, scale) with arg-max
+ * (scale = sample_scale <= 256, P = floor(L / scale) windows), its routing backward (times lrelu' of the pre-pool
+ * activation), nearest upsample x scale + pad (rem_half = (L - P*scale) / 2 on each side) + add and its backward.
+ * ABI 3: `scale` is an argument (ABI 2 fixed it at 80, the value of every shipped checkpoint).             */
+int stof_train_pool(const float* c, float* pooled, uint8_t* arg, int64_t N, int64_t L, int64_t P, int32_t C,
+                    int32_t scale, void* stream);
 int stof_train_pool_bwd(const float* gpool, const uint8_t* arg, const float* c, float* gc, int64_t N, int64_t L,
-                        int64_t P, int32_t C, void* stream);
+                        int64_t P, int32_t C, int32_t scale, void* stream);
 int stof_train_upsample_add(const float* a, const float* e, float* out, int64_t N, int64_t L, int64_t P,
-                            int32_t rem_half, void* stream);
+                            int32_t rem_half, int32_t scale, void* stream);
 int stof_train_upsample_bwd(const float* g, const float* e, float* ge, int64_t N, int64_t L, int64_t P,
-                            int32_t rem_half, void* stream);
+                            int32_t rem_half, int32_t scale, void* stream);
 /* Loss of main.py:228-232: target = amplitude * blur7(coords2mask(gt)) / max, loss = MSE + lambda * mean|pred|;
  * writes target[N*M], tmax[1], dpred[N*M] = grad_scale * dloss/dpred and loss[1] (double).  grad_scale is a power
  * of two (loss scaling: keeps the back-propagated values inside the fp16 range of the f16x3 mode); the weight-

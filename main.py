@@ -78,6 +78,14 @@ class RunLog:
 def load_frames(cfg):
     if cfg.input_file:
         arr = np.load(cfg.input_file).astype(np.float32)
+        if arr.ndim == 4:                                                # PALA loader output [B, waves, C, S]: main.py:301 takes wave wv_idx = 1 (main.py:71)
+            arr = arr[:, int(getattr(cfg, 'wave_index', 1))]
+        if arr.ndim == 3 and arr.shape[1] > 1:
+            # PALA-shaped frames [B, C, S]: NormalizeVol acts on the whole frame (utils/transforms.py:13), then
+            # `frame.reshape(-1, S).unsqueeze(1)` (main.py:301) -> [B*C, 1, S]; batch_size keeps counting frames
+            arr = arr / np.abs(arr).max(axis=(1, 2), keepdims=True)
+            cfg.rows_per_frame = int(arr.shape[1])
+            return arr.reshape(-1, 1, arr.shape[-1]), None
         arr = arr[:, None, :] if arr.ndim == 2 else arr
         return arr / np.abs(arr).max(axis=-1, keepdims=True), None     # NormalizeVol (utils/transforms.py:13)
     from stofnet_amd.synth import synth_echo          # deterministic demo inputs only
@@ -162,13 +170,45 @@ def train(model, frames, gt, cfg, log=None):
         g = torch.where(g <= 0, torch.zeros_like(g), g)                  # main.py:217
         return torch.round(g.unsqueeze(1) * r).long()                    # main.py:218
 
+    autograd = str(getattr(cfg, 'trainer', 'fused')) == 'autograd'
+    if autograd:
+        # the reference's own training lines (main.py:179-180,184-188,221-248,288) on the module's autograd boundary:
+        # torch loss, torch.optim.AdamW, CosineAnnealingLR; `loss.backward()` runs the stof_train_* kernels
+        import torch.nn.functional as F
+        from stofnet_amd.mask2samples import coords2mask
+        from stofnet_amd.training import allreduce_max_, allreduce_mean_, gaussian_kernel
+        model.train_precision = str(cfg.train_precision)
+        optimizer = torch.optim.AdamW(model.parameters(), lr=float(cfg.lr), weight_decay=float(cfg.weight_decay))
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, int(cfg.epochs))
+        loss_mse, loss_l1 = torch.nn.MSELoss(reduction='mean'), torch.nn.L1Loss(reduction='mean')
+        gauss = torch.tensor(gaussian_kernel(int(cfg.kernel_size), cfg.sigma), dtype=torch.float32,
+                             device=cfg.device).unsqueeze(0).unsqueeze(0)
+
+        def autograd_step(frame, gt_true):
+            masks_pred = model(frame)                                                            # main.py:221
+            masks_true = coords2mask(gt_true, masks_pred)                                        # main.py:228
+            blur = F.conv1d(masks_true, gauss, padding=int(cfg.kernel_size) // 2)                # main.py:229
+            blur = blur / allreduce_max_(blur.max().reshape(1))                                  # main.py:230 (whole batch, all ranks)
+            blur = blur * float(cfg.mask_amplitude)                                              # main.py:231
+            loss = (loss_mse(masks_pred.squeeze(1), blur.squeeze(1).float()) +
+                    loss_l1(masks_pred.squeeze(1), torch.zeros_like(masks_pred.squeeze(1))) * float(cfg.lambda_value))   # main.py:232
+            optimizer.zero_grad()                                                                # main.py:246
+            loss.backward()                                                                      # main.py:247
+            if world > 1:                                                                        # DDP: mean of the shard gradients
+                for prm in model.parameters():
+                    allreduce_mean_(prm.grad)
+            optimizer.step()                                                                     # main.py:248
+            return loss.detach(), masks_pred.detach()
+
     for e in range(int(cfg.epochs)):
-        tr.set_lr_cosine(e, int(cfg.epochs), float(cfg.lr))              # CosineAnnealingLR stepped per epoch
+        if not autograd:
+            tr.set_lr_cosine(e, int(cfg.epochs), float(cfg.lr))          # CosineAnnealingLR stepped per epoch
         model.train()
         tot = 0.0
         for b in mine:
             sl = slice(b * bs, (b + 1) * bs)
-            loss, _ = tr.train_step(torch.from_numpy(tr_x[sl]).to(cfg.device), gt_true_of(tr_gt[sl]))
+            step = autograd_step if autograd else tr.train_step
+            loss, _ = step(torch.from_numpy(tr_x[sl]).to(cfg.device), gt_true_of(tr_gt[sl]))
             tot += float(loss)
             if log is not None and log.enabled:
                 log.log({'train_step': e * len(mine) + (b - rank) // world + 1, 'train_loss': float(loss)})      # main.py:251-255
@@ -178,11 +218,14 @@ def train(model, frames, gt, cfg, log=None):
             for b0 in range(0, va_x.shape[0] - bs + 1, bs):
                 pred = model(torch.from_numpy(va_x[b0:b0 + bs]).to(cfg.device))
                 val += float(tr.loss(pred, gt_true_of(va_gt[b0:b0 + bs])))
-        history.append({'epoch': e, 'lr': tr.lr, 'train_loss': tot / max(len(mine), 1), 'val_loss': val})
+        lr_now = optimizer.param_groups[0]['lr'] if autograd else tr.lr
+        if autograd:
+            scheduler.step()                                                                                # main.py:288
+        history.append({'epoch': e, 'lr': lr_now, 'train_loss': tot / max(len(mine), 1), 'val_loss': val})
         if rank == 0:
             print(json.dumps(history[-1]))
         if log is not None:
-            log.log({'lr': tr.lr, 'epoch': e})                                                              # main.py:282-286
+            log.log({'lr': lr_now, 'epoch': e})                                                              # main.py:282-286
         if val < best - float(cfg.delta):                                # EarlyStopping (utils/early_stop.py)
             best, bad = val, 0
         else:
@@ -199,7 +242,7 @@ def train(model, frames, gt, cfg, log=None):
 
 
 def evaluate(model, name, frames, gt, cfg, log=None):
-    bs = int(cfg.batch_size)
+    bs = int(cfg.batch_size) * int(getattr(cfg, 'rows_per_frame', 1))      # PALA: a batch of B frames is B*C rows (main.py:301)
     results, times = [], []
     with torch.no_grad():
         for b0 in range(0, frames.shape[0] - bs + 1, bs):          # drop_last=True (main.py:111)

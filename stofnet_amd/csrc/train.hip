@@ -672,19 +672,19 @@ __global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ copies, floa
     if (d < 9) dw[ch * 9 + d] = s * out_scale; else db[ch] = s * out_scale;
 }
 
-// MaxPool1d(80, 80) over time of c[N][L][C] -> pooled[N][P][C] with the arg-max offset (first maximum)
+// MaxPool1d(S, S) (S = sample_scale, 80 in every shipped checkpoint) over time of c[N][L][C] -> pooled[N][P][C] with the arg-max offset (first maximum)
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ c, float* __restrict__ pooled,
-                                                       unsigned char* __restrict__ arg, int N, int L, int P, int C) {
+                                                       unsigned char* __restrict__ arg, int N, int L, int P, int C, int S) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;      // (n, w, ch)
     if (i >= (long long)N * P * C) return;
     const int ch = (int)(i % C);
     const long long nw = i / C;
     const int w = (int)(nw % P);
     const long long n = nw / P;
-    const float* src = c + (n * L + (long long)w * SGB_SCALE) * C + ch;
+    const float* src = c + (n * L + (long long)w * S) * C + ch;
     float best = src[0];
     int bi = 0;
-    for (int k = 1; k < SGB_SCALE; ++k) {
+    for (int k = 1; k < S; ++k) {
         const float v = src[(long long)k * C];
         if (v > best) { best = v; bi = k; }
     }
@@ -695,21 +695,21 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 // gc[N][L][C] = 0 except gc[n][80w + arg][ch] = gpool[n][w][ch] * lrelu'(c at that position)
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ gpool, const unsigned char* __restrict__ arg,
                                                        const float* __restrict__ c, float* __restrict__ gc,
-                                                       int N, int L, int P, int C) {
+                                                       int N, int L, int P, int C, int S) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= (long long)N * P * C) return;
     const int ch = (int)(i % C);
     const long long nw = i / C;
     const int w = (int)(nw % P);
     const long long n = nw / P;
-    const long long pos = (n * L + (long long)w * SGB_SCALE + arg[i]) * C + ch;
+    const long long pos = (n * L + (long long)w * S + arg[i]) * C + ch;
     const float s = c[pos];
     gc[pos] = s > 0.f ? gpool[i] : 0.01f * gpool[i];
 }
 
 // x0[n][t][ch] = a[n][t][ch] + e[n][w(t)][ch]   (nearest upsample x80, shifted by rem_half, zero outside)
 __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restrict__ a, const float* __restrict__ e,
-                                                           float* __restrict__ out, int N, int L, int P, int rem_half) {
+                                                           float* __restrict__ out, int N, int L, int P, int rem_half, int S) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;      // float4 index
     if (i >= (long long)N * L * 16) return;
     const int q = (int)(i & 15);
@@ -718,8 +718,8 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restri
     const long long n = nt / L;
     float4 v = ld4(a + nt * 64 + 4 * q);
     const int pos = t - rem_half;
-    if (pos >= 0 && pos < SGB_SCALE * P) {
-        const float4 s = ld4(e + (n * P + pos / SGB_SCALE) * 64 + 4 * q);
+    if (pos >= 0 && pos < S * P) {
+        const float4 s = ld4(e + (n * P + pos / S) * 64 + 4 * q);
         v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
     }
     *reinterpret_cast<float4*>(out + nt * 64 + 4 * q) = v;
@@ -727,16 +727,16 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restri
 
 // ge[n][w][ch] = lrelu'(e) * sum_{t in window w} g[n][t][ch]
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ g, const float* __restrict__ e,
-                                                           float* __restrict__ ge, int N, int L, int P, int rem_half) {
+                                                           float* __restrict__ ge, int N, int L, int P, int rem_half, int S) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;      // (n, w, ch)
     if (i >= (long long)N * P * 64) return;
     const int ch = (int)(i & 63);
     const long long nw = i >> 6;
     const int w = (int)(nw % P);
     const long long n = nw / P;
-    const float* src = g + (n * L + rem_half + (long long)w * SGB_SCALE) * 64 + ch;
+    const float* src = g + (n * L + rem_half + (long long)w * S) * 64 + ch;
     float s = 0.f;
-    for (int k = 0; k < SGB_SCALE; ++k) s += src[(long long)k * 64];
+    for (int k = 0; k < S; ++k) s += src[(long long)k * 64];
     ge[i] = e[i] > 0.f ? s : 0.01f * s;
 }
 
@@ -981,45 +981,45 @@ extern "C" int stof_train_conv1_wgrad(const float* x, const float* g, const floa
 }
 
 extern "C" int stof_train_pool(const float* c, float* pooled, uint8_t* arg, int64_t N, int64_t L, int64_t P, int32_t C,
-                               void* stream) {
-    if (N < 0 || L < 0 || P < 0 || C < 1 || P * SGB_SCALE > L) return STOF_ERR_BAD_ARG;
+                               int32_t scale, void* stream) {
+    if (N < 0 || L < 0 || P < 0 || C < 1 || scale < 1 || scale > 256 || P * scale > L) return STOF_ERR_BAD_ARG;
     if (N * P == 0) return STOF_OK;
     if (!c || !pooled || !arg) return STOF_ERR_BAD_ARG;
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(blocks_for(N * P * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       c, pooled, arg, (int)N, (int)L, (int)P, C);
+                       c, pooled, arg, (int)N, (int)L, (int)P, C, scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
 extern "C" int stof_train_pool_bwd(const float* gpool, const uint8_t* arg, const float* c, float* gc, int64_t N, int64_t L,
-                                   int64_t P, int32_t C, void* stream) {
-    if (N < 0 || L < 0 || P < 0 || C < 1) return STOF_ERR_BAD_ARG;
+                                   int64_t P, int32_t C, int32_t scale, void* stream) {
+    if (N < 0 || L < 0 || P < 0 || C < 1 || scale < 1 || scale > 256 || P * scale > L) return STOF_ERR_BAD_ARG;
     if (N * L == 0) return STOF_OK;
     if (!gpool || !arg || !c || !gc) return STOF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(gc, 0, (size_t)N * L * C * sizeof(float), s) != hipSuccess) return STOF_ERR_HIP;
     if (N * P > 0)
         hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for(N * P * C)), dim3(256), 0, s, gpool, arg, c, gc, (int)N, (int)L,
-                           (int)P, C);
+                           (int)P, C, scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
 extern "C" int stof_train_upsample_add(const float* a, const float* e, float* out, int64_t N, int64_t L, int64_t P,
-                                       int32_t rem_half, void* stream) {
-    if (N < 0 || L < 0 || P < 0) return STOF_ERR_BAD_ARG;
+                                       int32_t rem_half, int32_t scale, void* stream) {
+    if (N < 0 || L < 0 || P < 0 || scale < 1 || rem_half < 0 || rem_half + P * scale > L) return STOF_ERR_BAD_ARG;
     if (N * L == 0) return STOF_OK;
     if (!a || !out || (!e && P > 0)) return STOF_ERR_BAD_ARG;
     hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks_for(N * L * 16)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       a, e, out, (int)N, (int)L, (int)P, rem_half);
+                       a, e, out, (int)N, (int)L, (int)P, rem_half, scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
 extern "C" int stof_train_upsample_bwd(const float* g, const float* e, float* ge, int64_t N, int64_t L, int64_t P,
-                                       int32_t rem_half, void* stream) {
-    if (N < 0 || L < 0 || P < 0) return STOF_ERR_BAD_ARG;
+                                       int32_t rem_half, int32_t scale, void* stream) {
+    if (N < 0 || L < 0 || P < 0 || scale < 1 || rem_half < 0 || rem_half + P * scale > L) return STOF_ERR_BAD_ARG;
     if (N * P == 0) return STOF_OK;
     if (!g || !e || !ge) return STOF_ERR_BAD_ARG;
     hipLaunchKernelGGL(upsample_bwd_kernel, dim3(blocks_for(N * P * 64)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       g, e, ge, (int)N, (int)L, (int)P, rem_half);
+                       g, e, ge, (int)N, (int)L, (int)P, rem_half, scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

@@ -6,7 +6,13 @@ checkpoints load with `load_state_dict(strict=True)` (main.py:176-177) and
 `model.parameters()` / `.to(device)` / `.eval()` behave as in the reference.
 `forward` never calls those convs: it repacks the parameters once into the
 kernels' streaming layout (re-done when a parameter changes) and calls
-`stof_forward*`.  Inference only: the result carries no autograd graph.
+`stof_forward*`.
+
+In train mode with gradients enabled (`model.train()`, no `torch.no_grad()`: main.py:205,221) `forward` goes through
+an autograd boundary instead (`training.StofNetFunction`): the layer-by-layer training kernels keep their activations
+and `loss.backward()` runs the hand-written data-/weight-gradient kernels, delivering `.grad` for every nn.Parameter,
+so the reference's torch loss and `optim.AdamW` lines (main.py:228-248) work unchanged.  `train_precision`
+('fp32' | 'f16x3') selects the MFMA mode of that path.
 
 `precision` (not in the reference, whose arithmetic is ATen fp32) selects the MFMA mode:
   'auto'  (default) split-fp16 x3 operands with fp32 accumulation -- fp32-level accuracy at 3x the
@@ -47,13 +53,37 @@ class SemiGlobalBlock(nn.Module):
         self.expand_upsample = nn.Upsample(scale_factor=sample_scale, mode='nearest')
 
     def forward(self, x):
-        raise RuntimeError('SemiGlobalBlock is fused into the StofNet kernels; call StofNet.forward')
+        """models/stofnet.py:98-117 standalone: x [N, C, L] -> x + pad(upsample(lrelu(expand(maxpool(lrelu(contract(x))))))).
+        Inside StofNet the block is fused into the network kernels; this entry serves direct callers on the same
+        channel-last MFMA convolution, pooling and upsample-add kernels the training path uses (exact fp32).  The NCL <->
+        channel-last transposes at the boundary are torch copies.  C = in_channels = out_channels = 64 (the kernels'
+        row width); no autograd graph."""
+        from .training import TrainEngine
+        _lib.require_device(x, 'x')
+        cin = self.contract_conv.in_channels
+        if x.dim() != 3 or x.shape[1] != cin:
+            raise RuntimeError(f'expected input [N, {cin}, L], got {list(x.shape)}')
+        if cin != 64 or self.expand_conv.out_channels != 64 or self.contract_conv.kernel_size[0] != 5:
+            raise NotImplementedError('SemiGlobalBlock.forward: the gfx950 kernels serve 64 -> 64 channels, kernel size 5')
+        n, _, L = x.shape
+        S = int(self.sample_scale)
+        if L // S == 0:
+            raise RuntimeError(_lib.status_string(_lib.STOF_ERR_POOL_EMPTY))
+        p = L - L // S * S
+        if p % 2:
+            raise RuntimeError(f'The size of tensor a ({L}) must match the size of tensor b ({L - 1}) at non-singleton dimension 2')
+        eng = TrainEngine(x.device, 1, True, 'fp32', scale=S)
+        with torch.cuda.device(x.device):
+            a = x.detach().float().permute(0, 2, 1).contiguous()
+            out = eng._sgb_forward(a, eng._repack(self.contract_conv.weight.detach(), False), self.contract_conv.bias.detach(),
+                                   eng._repack(self.expand_conv.weight.detach(), False), self.expand_conv.bias.detach())[0]
+            return out.permute(0, 2, 1).contiguous()
 
 
 class StofNet(nn.Module):
 
     def __init__(self, upsample_factor=4, num_features=64, num_blocks=13, kernel_sizes=[9, 7, 3], in_channels=1,
-                 semi_global_scale=80, weights_init=False, precision='auto'):
+                 semi_global_scale=80, weights_init=False, precision='auto', train_precision='fp32'):
         super().__init__()
         self.num_blocks = num_blocks
         self.in_channels = in_channels
@@ -64,6 +94,10 @@ class StofNet(nn.Module):
         if precision not in _PRECISIONS:
             raise ValueError(f'precision must be one of {sorted(_PRECISIONS)}')
         self.precision = precision
+        if train_precision not in ('fp32', 'f16x3'):
+            raise ValueError("train_precision must be 'fp32' or 'f16x3'")
+        self.train_precision = train_precision
+        self._engines = {}
 
         self.conv1 = nn.Conv1d(in_channels, num_features, kernel_sizes[0], 1, 4)
         self.conv_last = nn.Conv1d(num_features, upsample_factor, kernel_sizes[-1], 1, 1)
@@ -82,8 +116,13 @@ class StofNet(nn.Module):
     # ---- kernel-side state -------------------------------------------------
     def _supported(self):
         return (self.num_features == 64 and self.num_blocks == 13 and list(self.kernel_sizes) == [9, 7, 3]
-                and self.in_channels == 1 and self.semi_global_scale in (1, 80)
+                and self.in_channels == 1 and (self.semi_global_scale == 1 or 2 <= self.semi_global_scale <= 256)
                 and 1 <= self.upsample_factor <= 64)
+
+    def _fused_sweep(self):
+        """The persistent LDS-resident sweep serves the shipped geometry (no SemiGlobalBlock, or sample_scale 80); any
+        other semi_global_scale runs layer by layer on the channel-last MFMA kernels of the training path."""
+        return self.semi_global_scale in (1, 80)
 
     def _param_list(self):
         ps = [self.conv1.weight, self.conv1.bias]
@@ -125,13 +164,17 @@ class StofNet(nn.Module):
     # ---- forward -------------------------------------------------------------
     def forward(self, x, _events=None):
         if not self._supported():
-            raise NotImplementedError('only the shipped StofNet architecture (64 features, 13 blocks, kernels '
-                                      '[9,7,3], 1 input channel, semi_global_scale in {1,80}) has gfx950 kernels')
+            raise NotImplementedError('only the shipped StofNet layout (64 features, 13 blocks, kernels [9,7,3], 1 input '
+                                      'channel; semi_global_scale 1 or 2..256) has gfx950 kernels')
         _lib.require_device(x, 'x')
         if x.dim() != 3 or x.shape[1] != self.in_channels:
             raise RuntimeError(f'expected input [N, {self.in_channels}, L], got {list(x.shape)}')
         n, _, L = x.shape
         r = int(self.upsample_factor)
+        if self.training and torch.is_grad_enabled() and _events is None and any(p.requires_grad for p in self.parameters()):
+            return self._forward_with_graph(x)
+        if not self._fused_sweep():
+            return self._forward_layerwise(x)
         xc = x.detach().contiguous().float()
         y = torch.empty((n, 1, L * r), dtype=torch.float32, device=x.device)
         lib = _lib.lib()
@@ -171,6 +214,40 @@ class StofNet(nn.Module):
         _lib.check(code, 'stof_forward')
         return y
 
+    def _engine(self, dev, precision):
+        from .training import TrainEngine
+        key = (str(dev), precision)
+        if key not in self._engines:
+            self._engines[key] = TrainEngine(dev, self.upsample_factor, self.semi_global_block is not None, precision,
+                                             scale=self.semi_global_scale if self.semi_global_block is not None else 80)
+        return self._engines[key]
+
+    def _forward_layerwise(self, x):
+        """Inference for a semi_global_scale other than 80 (models/stofnet.py:11 accepts any): every layer on the
+        channel-last MFMA kernels, activations dropped as soon as the next layer has consumed them.  'auto' maps to the
+        exact fp32 mode here (the range guard lives in the fused sweep)."""
+        if x.shape[0] == 0:
+            return torch.empty((0, 1, x.shape[-1] * int(self.upsample_factor)), dtype=torch.float32, device=x.device)
+        eng = self._engine(x.device, 'f16x3' if self.precision == 'f16x3' else 'fp32')
+        with torch.cuda.device(x.device):
+            pred, _ = eng._forward_saved({n: p.detach() for n, p in self.named_parameters()}, x, keep=False)
+        return pred.view(x.shape[0], 1, -1)
+
+    def _forward_with_graph(self, x):
+        """Train-mode forward (main.py:221): same numbers as the inference path to fp32 rounding, but every layer's
+        activation is kept and the result carries a grad_fn whose backward fills the parameters' gradients."""
+        from .training import StofNetFunction
+        if x.requires_grad:
+            raise NotImplementedError('StofNet: the gradient with respect to the input frame is not implemented '
+                                      '(the reference trains the parameters only); pass x.detach()')
+        if x.shape[0] == 0:
+            raise RuntimeError('StofNet: empty batch in train mode')
+        named = list(self.named_parameters())
+        dev = named[0][1].device
+        if dev != x.device:
+            raise RuntimeError(f'Input type ({x.device}) and weight type ({dev}) should be the same')
+        return StofNetFunction.apply(x, self._engine(dev, self.train_precision), tuple(n for n, _ in named), *[p for _, p in named])
+
     # ---- forward with the arg-max picker fused into the sweep ---------------------------------
     def forward_onsets(self, x, window_size=20, return_map=False, cap=32, sync=True):
         """`model(x)` followed by `get_maxima_positions(., window_size, threshold=None)` (main.py:314 -> 320 with th=Null)
@@ -196,7 +273,7 @@ class StofNet(nn.Module):
             counts, idx = onset_indices(y, window_size, None)
             return (counts, idx, y) if return_map else (counts, idx)
 
-        if not self._supported() or self.precision == 'fp32' or r > 16 or L < 32 or n == 0:
+        if not self._supported() or not self._fused_sweep() or self.precision == 'fp32' or r > 16 or L < 32 or n == 0:
             return via_map()
         desc = self._desc(_lib.PREC_F16X3)
         xc = x.detach().contiguous().float()

@@ -72,3 +72,25 @@ def synth_state_dict(r: int, seed: int, semi_global_scale: int = 80, num_feature
     for i in range(2, 13):
         conv(f'conv{i}', num_features, num_features, 7)
     return sd
+
+
+def pala_frames(B: int, C: int, S: int, seed: int):
+    """Synthetic PALA-like RF frame stack [B, C, S] (the reference's PALA loader yields [B, waves, C, S] and main.py:301
+    flattens one wave to [B*C, 1, S]; the dataset itself is an absent submodule): a few micro-bubble echoes per frame,
+    each arriving at a channel-dependent delay (hyperbolic move-out), long smooth pulses as after the x20 interpolation
+    (rf_scale_factor 20), NormalizeVol over the whole frame (utils/transforms.py:13)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(S, dtype=np.float64)[None, None, :]
+    ch = np.arange(C, dtype=np.float64)[None, :, None]
+    out = np.zeros((B, C, S))
+    for _ in range(3):
+        depth = rng.uniform(0.15, 0.7, size=(B, 1, 1)) * S
+        xpos = rng.uniform(0, C, size=(B, 1, 1))
+        delay = np.sqrt(depth ** 2 + (40.0 * (ch - xpos)) ** 2)
+        rel = t - delay
+        env = np.clip(rel / 300.0, 0, 1) * np.exp(-np.maximum(rel - 300.0, 0) / 900.0)
+        env[rel < 0] = 0
+        out += rng.uniform(0.4, 1.0, size=(B, 1, 1)) * env * np.sin(2 * np.pi * 0.004 * rel + rng.uniform(0, 6.28, size=(B, 1, 1)))
+    out += 0.0005 * rng.standard_normal(out.shape)
+    out /= np.abs(out).max(axis=(1, 2), keepdims=True)
+    return out.astype(np.float32)

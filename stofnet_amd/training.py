@@ -27,49 +27,24 @@ def gaussian_kernel(size, sigma=1.0):
     return k / np.sum(k)
 
 
-class StofNetTrainer:
-    """AdamW(lr, weight_decay) + MSE(pred, 20*blur7(onehot(gt))/max) + lambda*mean|pred| on `model`
-    (main.py:179,184-188,228-232,246-248).  The model's parameters are re-seated as views of one flat
-    buffer so the optimizer kernel and the gradient all-reduce touch a single tensor."""
+class TrainEngine:
+    """Layer-by-layer forward with saved activations and the full backward pass of StofNet on the gfx950 training
+    kernels (`stof_train_*`), on explicit parameter / gradient dictionaries.  Shared by `StofNetTrainer` (fused loss
+    kernels + AdamW kernel on one flat buffer) and by the autograd boundary of `StofNet.forward` in train mode
+    (`StofNetFunction`: torch computes the loss and owns the optimizer, as in the reference's main.py:221-248)."""
 
-    def __init__(self, model: StofNet, lr=5e-4, weight_decay=1e-8, lambda_value=1e-2, mask_amplitude=20,
-                 kernel_size=7, sigma=1, betas=(0.9, 0.999), eps=1e-8, process_group=None, precision='fp32'):
-        if not model._supported():
-            raise NotImplementedError('only the shipped StofNet architecture is supported')
-        if kernel_size != 7:
-            raise NotImplementedError('the loss kernel implements the 7-tap blur of config.yaml:23')
+    def __init__(self, dev, r, sgb, precision='fp32', scale=80):
         if precision not in ('fp32', 'f16x3'):
             raise ValueError("precision must be 'fp32' or 'f16x3'")
         self.prec = 1 if precision == 'f16x3' else 0       # arithmetic of every 64/512-channel convolution: forward, data gradient, weight gradient
-        self.model = model
-        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
-        self.lam, self.amp = float(lambda_value), float(mask_amplitude)
-        self.group = process_group
-        self.target_max_hook = None      # tests: stands in for the MAX all-reduce of the blurred-target maximum
-        self.step_count = 0
+        self.dev, self.r, self.sgb = dev, int(r), bool(sgb)
+        # SemiGlobalBlock geometry (models/stofnet.py:83-85): pool / upsample by `scale`, feat_scale = max(1, scale // 10)
+        self.scale = int(scale)
+        self.cmid = 64 * max(1, self.scale // 10)
+        if self.sgb and not 2 <= self.scale <= 256:
+            raise NotImplementedError('SemiGlobalBlock sample_scale must be in [2, 256] for the gfx950 kernels')
         self._gscale = 1.0
-        params = list(model.named_parameters())
-        dev = params[0][1].device
-        _lib.require_device(params[0][1], 'model parameters')
-        self.names = [n for n, _ in params]
-        sizes = [p.numel() for _, p in params]
-        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros_like(self.flat)
-        self.exp_avg = torch.zeros_like(self.flat)
-        self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.p, self.g = {}, {}
-        off = 0
-        for (name, prm), n in zip(params, sizes):
-            view = self.flat[off:off + n].view(prm.shape)
-            view.copy_(prm.data)
-            prm.data = view                                   # the module now lives in the flat buffer
-            self.p[name] = view
-            self.g[name] = self.flat_grad[off:off + n].view(prm.shape)
-            off += n
-        self.taps = torch.tensor(gaussian_kernel(kernel_size, sigma), dtype=torch.float32, device=dev)
-        self.dev = dev
-        self.r = int(model.upsample_factor)
-        self.sgb = model.semi_global_block is not None
+        self.g = {}
 
     # ---- thin wrappers over the C ABI ---------------------------------------------------------
     def _st(self):
@@ -107,47 +82,209 @@ class StofNetTrainer:
         _lib.check(_lib.lib().stof_train_add(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), self._st()), 'stof_train_add')
         return out
 
+    # ---- forward (activations kept) and backward, on explicit parameter / gradient dictionaries --------------
+    def _forward_saved(self, p, frame, keep=True):
+        """models/stofnet.py:42-67 layer by layer, every activation kept for the backward pass.
+        Returns (pred [N, L*r] = conv_last's channel-last output = the sample-shuffled prediction, saved)."""
+        lib = _lib.lib()
+        _lib.require_device(frame, 'frame')
+        r = self.r
+        x = frame.detach().reshape(frame.shape[0], frame.shape[-1]).contiguous().float()
+        n, L = x.shape
+        S, cm = self.scale, self.cmid
+        P = L // S if self.sgb else 0
+        rem = L - S * P
+        if self.sgb and P == 0:
+            raise RuntimeError(_lib.status_string(_lib.STOF_ERR_POOL_EMPTY))     # the reference's max_pool1d error
+        if self.sgb and rem % 2:
+            raise RuntimeError(f'The size of tensor a ({L}) must match the size of tensor b ({L - 1}) at non-singleton dimension 2')
+        sg = 'semi_global_block.'
+        st = self._st()
+        fwd = {k[:-7]: self._repack(v, False) for k, v in p.items() if k.endswith('.weight') and k != 'conv1.weight'}
+        bwd = {k[:-7]: self._repack(v, True) for k, v in p.items() if k.endswith('.weight') and k != 'conv1.weight'} if keep else None
+        a1 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
+        _lib.check(lib.stof_train_conv1(_lib.ptr(x), _lib.ptr(p['conv1.weight']), _lib.ptr(p['conv1.bias']), _lib.ptr(a1),
+                                        n, L, st), 'stof_train_conv1')
+        c = pooled = arg = e = None
+        if self.sgb:
+            x0, c, pooled, arg, e = self._sgb_forward(a1, fwd[sg + 'contract_conv'], p[sg + 'contract_conv.bias'],
+                                                      fwd[sg + 'expand_conv'], p[sg + 'expand_conv.bias'])
+        else:
+            x0 = a1
+        if not keep:
+            del c, pooled, arg, e
+            c = pooled = arg = e = None
+        xs, ys = [x0], []
+        for k in range(5):
+            ys.append(self._conv(xs[-1], fwd[f'conv{2 * k + 2}'], p[f'conv{2 * k + 2}.bias'], 64, 64, 7, ACT_LRELU))
+            xs.append(self._conv(ys[-1], fwd[f'conv{2 * k + 3}'], p[f'conv{2 * k + 3}.bias'], 64, 64, 7, ACT_NONE, residual=xs[-1]))
+            if not keep:
+                ys[-1] = None
+                if k > 0:
+                    xs[k] = None
+        x6 = self._conv(xs[5], fwd['conv12'], p['conv12.bias'], 64, 64, 7, ACT_NONE, residual=x0)
+        z = self._conv(x6, fwd['conv_last'], p['conv_last.bias'], 64, r, 3, ACT_NONE)      # [N, L, r] == shuffled [N, L*r]
+        if not keep:
+            return z.view(n, L * r), None
+        saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=x6, bwd=bwd, n=n, L=L, P=P, rem=rem)
+        return z.view(n, L * r), saved
+
+    def _sgb_forward(self, a1, w_contract, b_contract, w_expand, b_expand):
+        """SemiGlobalBlock.forward (models/stofnet.py:98-117) on channel-last a1 [N, L, 64]:
+        a1 + pad(upsample(lrelu(expand(maxpool(lrelu(contract(a1))))))).  Returns (out, c, pooled, arg, e)."""
+        lib, st = _lib.lib(), self._st()
+        n, L = a1.shape[0], a1.shape[1]
+        S, cm = self.scale, self.cmid
+        P = L // S
+        rem = L - S * P
+        c = self._conv(a1, w_contract, b_contract, 64, cm, 5, ACT_LRELU)
+        pooled = torch.empty((n, max(P, 1), cm), dtype=torch.float32, device=self.dev)[:, :P]
+        arg = torch.empty((n, max(P, 1), cm), dtype=torch.uint8, device=self.dev)[:, :P]
+        _lib.check(lib.stof_train_pool(_lib.ptr(c), _lib.ptr(pooled), _lib.ptr(arg), n, L, P, cm, S, st), 'stof_train_pool')
+        e = self._conv(pooled, w_expand, b_expand, cm, 64, 5, ACT_LRELU)
+        out = torch.empty_like(a1)
+        _lib.check(lib.stof_train_upsample_add(_lib.ptr(a1), _lib.ptr(e), _lib.ptr(out), n, L, P, rem // 2, S, st),
+                   'stof_train_upsample_add')
+        return out, c, pooled, arg, e
+
+    def _backward_saved(self, saved, dpred, g, gscale):
+        """Backward pass from dpred [N, L*r] = gscale * dloss/dpred (gscale a power of two: the f16x3 data-gradient
+        convolutions would otherwise work on fp16 subnormals; the weight-gradient kernels multiply by 1/gscale, exact).
+        Writes every parameter gradient into the tensors of `g` (name -> tensor of the parameter's shape)."""
+        lib = _lib.lib()
+        r, st = self.r, self._st()
+        sg = 'semi_global_block.'
+        n, L, P, rem = saved['n'], saved['L'], saved['P'], saved['rem']
+        xs, ys, x6, bwd, a1 = saved['xs'], saved['ys'], saved['x6'], saved['bwd'], saved['a1']
+        self._gscale = float(gscale)
+        self.g = g
+        dz = dpred.view(n, L, r)
+        self._wgrad(x6, dz, 'conv_last', 64, r, 3)
+        g6 = self._conv(dz, bwd['conv_last'], None, r, 64, 3)
+        self._wgrad(xs[5], g6, 'conv12', 64, 64, 7)
+        gg = self._conv(g6, bwd['conv12'], None, 64, 64, 7)                       # d/dx5
+        for k in range(4, -1, -1):
+            nb, na = f'conv{2 * k + 3}', f'conv{2 * k + 2}'
+            self._wgrad(ys[k], gg, nb, 64, 64, 7)
+            u = self._conv(gg, bwd[nb], None, 64, 64, 7, ACT_LRELU, saved=ys[k])  # d/d(pre-activation of conv_a)
+            self._wgrad(xs[k], u, na, 64, 64, 7)
+            gg = self._conv(u, bwd[na], None, 64, 64, 7, residual=gg)             # d/dx_k
+        g_x0 = self._add(gg, g6)                                                  # long skip res1 (models/stofnet.py:62)
+        if self.sgb and P:
+            e, pooled, arg, c = saved['e'], saved['pooled'], saved['arg'], saved['c']
+            ge = torch.empty((n, P, 64), dtype=torch.float32, device=self.dev)
+            S, cm = self.scale, self.cmid
+            _lib.check(lib.stof_train_upsample_bwd(_lib.ptr(g_x0), _lib.ptr(e), _lib.ptr(ge), n, L, P, rem // 2, S, st),
+                       'stof_train_upsample_bwd')
+            self._wgrad(pooled, ge, sg + 'expand_conv', cm, 64, 5)
+            gpool = self._conv(ge, bwd[sg + 'expand_conv'], None, 64, cm, 5)
+            gc = torch.empty_like(c)
+            _lib.check(lib.stof_train_pool_bwd(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(c), _lib.ptr(gc), n, L, P, cm, S, st),
+                       'stof_train_pool_bwd')
+            self._wgrad(a1, gc, sg + 'contract_conv', 64, cm, 5)
+            g_a1 = self._conv(gc, bwd[sg + 'contract_conv'], None, cm, 64, 5, residual=g_x0)
+        else:
+            g_a1 = g_x0
+        ws1 = torch.empty(lib.stof_train_conv1_wgrad_workspace_bytes(), dtype=torch.uint8, device=self.dev)
+        _lib.check(lib.stof_train_conv1_wgrad(_lib.ptr(saved['x']), _lib.ptr(g_a1), _lib.ptr(a1), _lib.ptr(g['conv1.weight']),
+                                              _lib.ptr(g['conv1.bias']), n, L, 1.0 / self._gscale, _lib.ptr(ws1),
+                                              ws1.numel(), st), 'stof_train_conv1_wgrad')
+
+
+class StofNetFunction(torch.autograd.Function):
+    """Autograd boundary of the train-mode forward: `masks_pred = model(frame)` (main.py:221) returns a tensor whose
+    `backward()` runs the `stof_train_*` data- and weight-gradient kernels and hands torch the gradient of every
+    `nn.Parameter`, so the reference's own lines -- torch loss (main.py:228-232), `optimizer.zero_grad();
+    loss.backward(); optimizer.step()` with `optim.AdamW` and `CosineAnnealingLR` (main.py:179-180,246-248,288) -- run
+    unchanged.  The gradient with respect to the input frame is not provided (the reference never asks for it)."""
+
+    @staticmethod
+    def forward(ctx, frame, engine, names, *params):
+        p = dict(zip(names, params))
+        with torch.cuda.device(engine.dev):
+            pred, saved = engine._forward_saved({k: v.detach() for k, v in p.items()}, frame)
+        ctx.engine, ctx.names, ctx.saved = engine, names, saved
+        ctx.shapes = [tuple(v.shape) for v in params]
+        n, m = pred.shape
+        return pred.view(n, 1, m)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        engine, saved = ctx.engine, ctx.saved
+        if saved is None:
+            raise RuntimeError('Trying to backward through the graph a second time: the saved activations of '
+                               'StofNet.forward have been freed')
+        n, m = saved['n'], saved['L'] * engine.r
+        with torch.cuda.device(engine.dev):
+            dpred = grad_out.detach().reshape(n, m).contiguous().float()
+            gscale = 1.0
+            if engine.prec == 1:
+                # dloss/dpred of a mean-reduced loss is ~1e-6: fp16-subnormal for the split-fp16 data-gradient
+                # convolutions.  Scale by the power of two that brings the largest entry to [1, 2) (exact); the
+                # weight-gradient kernels multiply by 1/scale (exact).  One host read per step.
+                amax = float(dpred.abs().amax())
+                if amax > 0.0 and math.isfinite(amax):
+                    gscale = 2.0 ** (-math.floor(math.log2(amax)))
+                    dpred = dpred * gscale
+            sizes = [int(np.prod(sh)) if len(sh) else 1 for sh in ctx.shapes]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=engine.dev)    # fresh: torch may keep these views as .grad
+            g, off = {}, 0
+            for name, sh, k in zip(ctx.names, ctx.shapes, sizes):
+                g[name] = flat[off:off + k].view(sh)
+                off += k
+            engine._backward_saved(saved, dpred, g, gscale)
+        ctx.saved = None
+        return (None, None, None) + tuple(g[name] for name in ctx.names)
+
+
+class StofNetTrainer(TrainEngine):
+    """AdamW(lr, weight_decay) + MSE(pred, 20*blur7(onehot(gt))/max) + lambda*mean|pred| on `model`
+    (main.py:179,184-188,228-232,246-248).  The model's parameters are re-seated as views of one flat
+    buffer so the optimizer kernel and the gradient all-reduce touch a single tensor."""
+
+    def __init__(self, model: StofNet, lr=5e-4, weight_decay=1e-8, lambda_value=1e-2, mask_amplitude=20,
+                 kernel_size=7, sigma=1, betas=(0.9, 0.999), eps=1e-8, process_group=None, precision='fp32'):
+        if not model._supported():
+            raise NotImplementedError('only the shipped StofNet architecture is supported')
+        if kernel_size != 7:
+            raise NotImplementedError('the loss kernel implements the 7-tap blur of config.yaml:23')
+        params = list(model.named_parameters())
+        super().__init__(params[0][1].device, model.upsample_factor, model.semi_global_block is not None, precision,
+                         scale=model.semi_global_scale if model.semi_global_block is not None else 80)
+        self.model = model
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
+        self.lam, self.amp = float(lambda_value), float(mask_amplitude)
+        self.group = process_group
+        self.target_max_hook = None      # tests: stands in for the MAX all-reduce of the blurred-target maximum
+        self.step_count = 0
+        dev = self.dev
+        _lib.require_device(params[0][1], 'model parameters')
+        self.names = [n for n, _ in params]
+        sizes = [p.numel() for _, p in params]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros_like(self.flat)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.p, self.g = {}, {}
+        off = 0
+        for (name, prm), n in zip(params, sizes):
+            view = self.flat[off:off + n].view(prm.shape)
+            view.copy_(prm.data)
+            prm.data = view                                   # the module now lives in the flat buffer
+            self.p[name] = view
+            self.g[name] = self.flat_grad[off:off + n].view(prm.shape)
+            off += n
+        self._grad_views = self.g
+        self.taps = torch.tensor(gaussian_kernel(kernel_size, sigma), dtype=torch.float32, device=dev)
+
     # ---- forward + loss + backward -----------------------------------------------------------
     def forward_backward(self, frame: torch.Tensor, gt_true: torch.Tensor):
         """frame [N,1,L] fp32, gt_true [N,1,G] int64 (round(gt_sample * r), main.py:218).  Fills the
         gradient buffer and returns (loss as a 0-d float64 device tensor, masks_pred [N,1,L*r])."""
-        lib = _lib.lib()
-        _lib.require_device(frame, 'frame')
-        p, r = self.p, self.r
-        x = frame.detach().reshape(frame.shape[0], frame.shape[-1]).contiguous().float()
-        n, L = x.shape
-        P = L // 80 if self.sgb else 0
-        rem = L - 80 * P
-        if self.sgb and rem % 2:
-            raise RuntimeError(f'The size of tensor a ({L}) must match the size of tensor b ({L - 1}) at non-singleton dimension 2')
         with torch.cuda.device(self.dev):
-            st = self._st()
             self.flat_grad.zero_()
-            fwd = {k[:-7]: self._repack(v, False) for k, v in p.items() if k.endswith('.weight') and k != 'conv1.weight'}
-            bwd = {k[:-7]: self._repack(v, True) for k, v in p.items() if k.endswith('.weight') and k != 'conv1.weight'}
-            # ---------------- forward (models/stofnet.py:42-67), activations kept
-            a1 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
-            _lib.check(lib.stof_train_conv1(_lib.ptr(x), _lib.ptr(p['conv1.weight']), _lib.ptr(p['conv1.bias']), _lib.ptr(a1),
-                                            n, L, st), 'stof_train_conv1')
-            if self.sgb:
-                sg = 'semi_global_block.'
-                c = self._conv(a1, fwd[sg + 'contract_conv'], p[sg + 'contract_conv.bias'], 64, 512, 5, ACT_LRELU)
-                pooled = torch.empty((n, max(P, 1), 512), dtype=torch.float32, device=self.dev)[:, :P]
-                arg = torch.empty((n, max(P, 1), 512), dtype=torch.uint8, device=self.dev)[:, :P]
-                _lib.check(lib.stof_train_pool(_lib.ptr(c), _lib.ptr(pooled), _lib.ptr(arg), n, L, P, 512, st), 'stof_train_pool')
-                e = self._conv(pooled, fwd[sg + 'expand_conv'], p[sg + 'expand_conv.bias'], 512, 64, 5, ACT_LRELU) if P else pooled[..., :64]
-                x0 = torch.empty_like(a1)
-                _lib.check(lib.stof_train_upsample_add(_lib.ptr(a1), _lib.ptr(e), _lib.ptr(x0), n, L, P, rem // 2, st),
-                           'stof_train_upsample_add')
-            else:
-                x0 = a1
-            xs, ys = [x0], []
-            for k in range(5):
-                ys.append(self._conv(xs[-1], fwd[f'conv{2 * k + 2}'], p[f'conv{2 * k + 2}.bias'], 64, 64, 7, ACT_LRELU))
-                xs.append(self._conv(ys[-1], fwd[f'conv{2 * k + 3}'], p[f'conv{2 * k + 3}.bias'], 64, 64, 7, ACT_NONE, residual=xs[-1]))
-            x6 = self._conv(xs[5], fwd['conv12'], p['conv12.bias'], 64, 64, 7, ACT_NONE, residual=x0)
-            z = self._conv(x6, fwd['conv_last'], p['conv_last.bias'], 64, r, 3, ACT_NONE)      # [N, L, r] == shuffled [N, L*r]
-            pred = z.view(n, L * r)
+            pred, saved = self._forward_saved(self.p, frame)
+            n, m = pred.shape
             # ---------------- loss (main.py:228-232)
             gt = gt_true.detach().reshape(n, -1).contiguous().to(self.dev, torch.int64)
             target = torch.empty_like(pred)
@@ -156,39 +293,10 @@ class StofNetTrainer:
             loss = torch.empty(1, dtype=torch.float64, device=self.dev)
             # loss scaling by a power of two (exact): dloss/dpred ~ 2*diff/(N*M) would sit in the fp16 subnormal range of
             # the f16x3 data-gradient convolutions; the weight-gradient kernels undo it with 1/scale
-            self._gscale = 2.0 ** math.floor(math.log2(max(n * L * r / 8.0, 1.0)))
-            self._loss_kernels(pred, gt, n, L * r, self._gscale, target, tmax, dpred, loss)
-            # ---------------- backward
-            dz = dpred.view(n, L, r)
-            self._wgrad(x6, dz, 'conv_last', 64, r, 3)
-            g6 = self._conv(dz, bwd['conv_last'], None, r, 64, 3)
-            self._wgrad(xs[5], g6, 'conv12', 64, 64, 7)
-            g = self._conv(g6, bwd['conv12'], None, 64, 64, 7)                       # d/dx5
-            for k in range(4, -1, -1):
-                nb, na = f'conv{2 * k + 3}', f'conv{2 * k + 2}'
-                self._wgrad(ys[k], g, nb, 64, 64, 7)
-                u = self._conv(g, bwd[nb], None, 64, 64, 7, ACT_LRELU, saved=ys[k])  # d/d(pre-activation of conv_a)
-                self._wgrad(xs[k], u, na, 64, 64, 7)
-                g = self._conv(u, bwd[na], None, 64, 64, 7, residual=g)              # d/dx_k
-            g_x0 = self._add(g, g6)                                                  # long skip res1 (models/stofnet.py:62)
-            if self.sgb and P:
-                ge = torch.empty((n, P, 64), dtype=torch.float32, device=self.dev)
-                _lib.check(lib.stof_train_upsample_bwd(_lib.ptr(g_x0), _lib.ptr(e), _lib.ptr(ge), n, L, P, rem // 2, st),
-                           'stof_train_upsample_bwd')
-                self._wgrad(pooled, ge, sg + 'expand_conv', 512, 64, 5)
-                gpool = self._conv(ge, bwd[sg + 'expand_conv'], None, 64, 512, 5)
-                gc = torch.empty_like(c)
-                _lib.check(lib.stof_train_pool_bwd(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(c), _lib.ptr(gc), n, L, P, 512, st),
-                           'stof_train_pool_bwd')
-                self._wgrad(a1, gc, sg + 'contract_conv', 64, 512, 5)
-                g_a1 = self._conv(gc, bwd[sg + 'contract_conv'], None, 512, 64, 5, residual=g_x0)
-            else:
-                g_a1 = g_x0
-            ws1 = torch.empty(lib.stof_train_conv1_wgrad_workspace_bytes(), dtype=torch.uint8, device=self.dev)
-            _lib.check(lib.stof_train_conv1_wgrad(_lib.ptr(x), _lib.ptr(g_a1), _lib.ptr(a1), _lib.ptr(self.g['conv1.weight']),
-                                                  _lib.ptr(self.g['conv1.bias']), n, L, 1.0 / self._gscale, _lib.ptr(ws1),
-                                                  ws1.numel(), st), 'stof_train_conv1_wgrad')
-        return loss[0], pred.view(n, 1, L * r)
+            gscale = 2.0 ** math.floor(math.log2(max(n * m / 8.0, 1.0)))
+            self._loss_kernels(pred, gt, n, m, gscale, target, tmax, dpred, loss)
+            self._backward_saved(saved, dpred, self._grad_views, gscale)
+        return loss[0], pred.view(n, 1, m)
 
     def loss(self, masks_pred: torch.Tensor, gt_true: torch.Tensor) -> torch.Tensor:
         """Loss value only (validation, main.py:322-327) for predictions [N,1,M]."""

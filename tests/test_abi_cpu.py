@@ -26,7 +26,7 @@ def test_exports_match_header(lib):
     for sym in sorted(declared):
         assert hasattr(lib, sym), f'{sym} declared in include/stofnet_amd.h but not exported'
     assert set(_lib.EXPORTED_SYMBOLS) == declared
-    assert lib.stof_abi_version() == 2
+    assert lib.stof_abi_version() == 3
     assert _lib.status_string(0) == 'ok'
     assert 'must match the size of tensor b' in _lib.status_string(_lib.STOF_ERR_ODD_SGB_REMAINDER)
 

@@ -923,3 +923,76 @@ def test_main_logging_switch_without_wandb(dev):
             os.remove(path)
     entry.main(['model=stofnet', 'th=Null', 'evaluate=True', 'batch_size=4', 'num_waveforms=4', 'num_samples=400'])   # logging: False
     assert not os.path.exists(path)
+
+
+# ---------------------------------------------------------------- round 3: API widening (VERDICT r2 missing 2-4)
+def _sgb_input(n, L, seed):
+    return np.random.default_rng(seed).standard_normal((n, 64, L)).astype(np.float32)
+
+
+@pytest.mark.parametrize('L', [2000, 1536, 160])
+def test_semi_global_block_forward_standalone(dev, L):
+    """SemiGlobalBlock.forward called directly (models/stofnet.py:98-117), [N,64,L] -> [N,64,L], with the checkpoint's
+    block: the reference's output (tests/golden/make_golden_r3.py sgb_standalone), and its errors."""
+    g = golden('f13_sgb_standalone')
+    m = make_model(dev, load_weights('different-armadillo'), 4)
+    blk = m.semi_global_block
+    y = blk(torch.from_numpy(_sgb_input(2, L, 1300 + L)).to(dev))
+    assert tuple(y.shape) == (2, 64, L)
+    want = g[f'y80_L{L}']
+    assert np.abs(y.cpu().numpy()[..., ::5] - want).max() < MAP_TOL * np.abs(want).max()
+    with pytest.raises(RuntimeError, match='must match the size of tensor b'):          # Q1, odd remainder
+        blk(torch.from_numpy(_sgb_input(1, 2001, 1)).to(dev))
+    with pytest.raises(RuntimeError):                                                      # fewer samples than one pooling window
+        blk(torch.from_numpy(_sgb_input(1, 40, 1)).to(dev))
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3', 'auto'])
+@pytest.mark.parametrize('scale', [40, 20])
+def test_other_semi_global_scales(dev, scale, precision):
+    """StofNet(semi_global_scale=40 / 20) (models/stofnet.py:11 accepts any scale; feat_scale = scale // 10): forward on
+    the layer-by-layer MFMA kernels equals the reference's; the standalone block with that scale too."""
+    g = golden('f13_sgb_standalone')
+    sd = synth.synth_state_dict(4, seed=3000 + scale, semi_global_scale=scale)
+    m = make_model(dev, sd, 4, sgs=scale, precision=precision)
+    for L in (2000, 1536):
+        y = m(torch.from_numpy(synth.synth_echo(2, L, seed=scale + L)).to(dev)).cpu().numpy()
+        want = g[f'net{scale}_y_L{L}']
+        assert y.shape == want.shape and rel_err(y, want) < MAP_TOL
+        assert np.array_equal(y[:, 0].argmax(-1), want[:, 0].argmax(-1))
+    yb = m.semi_global_block(torch.from_numpy(_sgb_input(2, 1000, 1300 + scale)).to(dev)).cpu().numpy()
+    assert np.abs(yb[..., ::5] - g[f'y{scale}_L1000']).max() < MAP_TOL * np.abs(g[f'y{scale}_L1000']).max()
+    from stofnet_amd.mask2samples import onset_indices
+    x = torch.from_numpy(synth.synth_echo(3, 800, seed=3)).to(dev)
+    c, i = m.forward_onsets(x, 20)
+    c2, i2 = onset_indices(m(x), 20, None)
+    assert torch.equal(c, c2) and torch.equal(i, i2)
+
+
+@pytest.mark.parametrize('thn,th', [('1em5', 1e-5), ('1em4', 1e-4)])
+def test_pala_gradpeak_configuration_end_to_end(dev, tmp_path, thn, th):
+    """`python main.py model=gradpeak data_dir=<pala> rf_scale_factor=20 th=1e-5` (bash_scripts/array_pala_params.txt:7) on a
+    PALA-shaped input file [B, C, S]: main.py:301 flattens the frames to [B*C, 1, S], GradPeak(echo_max=inf, onset_opt=False)
+    returns the PEAK column -- identical to the reference (tests/golden/make_golden_r3.py pala_gradpeak)."""
+    import main as entry
+    from stofnet_amd import GradPeak
+    g = golden('f12_pala_gradpeak')
+    B, C, S, seed = (int(g[k]) for k in ('B', 'C', 'S', 'seed'))
+    frames = synth.pala_frames(B, C, S, seed)
+    path = tmp_path / 'pala_frames.npy'
+    np.save(path, frames)
+    es, summary = entry.main(['model=gradpeak', f'input_file={path}', 'data_dir=/data/PALA_data_InSilicoFlow', 'rf_scale_factor=20',
+                              f'th={th}', 'batch_size=1'])
+    want = g[f'peaks_th{thn}']
+    assert summary['waveforms'] == B * C
+    k = max(es.shape[1], want.shape[1])
+    pad = lambda a: np.pad(a, ((0, 0), (0, k - a.shape[1])))
+    assert np.array_equal(pad(es), pad(want))
+    x = torch.from_numpy(frames.reshape(-1, 1, S)).to(dev)
+    onsets = GradPeak(threshold=th, rescale_factor=20, echo_max=float('inf'), onset_opt=True)(x).cpu().numpy()
+    assert np.array_equal(onsets, g[f'onsets_th{thn}'])
+    # a [B, waves, C, S] file: main.py:301 takes wave index 1
+    np.save(path, np.stack([np.zeros_like(frames), frames, 2 * frames], 1))
+    es4, _ = entry.main(['model=gradpeak', f'input_file={path}', 'data_dir=/data/PALA_data_InSilicoFlow', 'rf_scale_factor=20',
+                         f'th={th}', 'batch_size=2'])
+    assert np.array_equal(pad(es4), pad(want))

@@ -152,6 +152,125 @@ def test_training_matches_reference_golden_f8(dev, precision):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_reference_training_lines_run_unchanged_on_the_module(dev, precision):
+    """The reference's own training lines -- `masks_pred = model(frame)` (main.py:221), coords2mask / blur / MSE + L1 in
+    torch (main.py:228-232), `optimizer.zero_grad(); loss.backward(); optimizer.step()` with torch.optim.AdamW
+    (main.py:179,246-248) -- on the GPU module: the train-mode forward is an autograd boundary whose backward runs the
+    stof_train_* kernels.  Same bars as the fused trainer against the reference's two real steps (f8_training)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from conftest import golden, load_weights
+    from stofnet_amd import StofNet
+    from stofnet_amd.mask2samples import coords2mask
+    from stofnet_amd.training import gaussian_kernel
+    g = golden('f8_training')
+    sd = load_weights('different-armadillo')
+    model = StofNet(upsample_factor=4, semi_global_scale=80, train_precision=precision)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(dev)
+    lr, wd, lam, amp, ks, sigma = g['hyper']
+    optimizer = torch.optim.AdamW(model.parameters(), lr=float(lr), weight_decay=float(wd))
+    loss_mse, loss_l1 = nn.MSELoss(reduction='mean'), nn.L1Loss(reduction='mean')
+    gauss_kernel_1d = torch.tensor(gaussian_kernel(size=int(ks), sigma=float(sigma)), dtype=torch.float32, device=dev).unsqueeze(0).unsqueeze(0)
+    frame, gt_true = torch.from_numpy(g['frame']).to(dev), torch.from_numpy(g['gt_true']).to(dev)
+    model.train()
+    losses = []
+    for it in range(2):
+        masks_pred = model(frame)
+        assert masks_pred.requires_grad and masks_pred.grad_fn is not None
+        masks_true = coords2mask(gt_true.clone(), masks_pred)
+        masks_true_blur = F.conv1d(masks_true, gauss_kernel_1d, padding=int(ks) // 2)
+        masks_true_blur /= masks_true_blur.max()
+        masks_true_blur *= float(amp)
+        loss = loss_mse(masks_pred.squeeze(1), masks_true_blur.squeeze(1).float()) + \
+            loss_l1(masks_pred.squeeze(1), torch.zeros_like(masks_pred.squeeze(1))) * float(lam)
+        optimizer.zero_grad()
+        loss.backward()
+        if it == 0:
+            assert relerr(masks_pred.detach().cpu().numpy(), g['masks_pred']) < 1e-5
+            for name, prm in model.named_parameters():
+                assert prm.grad is not None and prm.grad.shape == prm.shape
+                assert relerr(prm.grad.cpu().numpy(), g['grad.' + name]) < 2e-4, name
+        optimizer.step()
+        losses.append(float(loss))
+    assert abs(losses[0] - float(g['loss0'])) < 2e-6 * float(g['loss0'])
+    assert abs(losses[1] - float(g['loss1'])) < 1e-4 * float(g['loss1'])
+    params = dict(model.named_parameters())
+    for key in g.files:
+        if key.startswith('after2.'):
+            diff = np.abs(params[key[7:]].detach().cpu().numpy() - g[key])
+            g0 = np.abs(g['grad.' + key[7:]])
+            assert diff[g0 > 1e-2 * g0.max()].max() < 2e-5, key
+            assert diff.max() < 1e-3 and (diff > 5e-5).mean() < 1e-3, key
+    # eval mode afterwards: the inference sweep with the UPDATED weights (the packed blob follows the parameters'
+    # versions), no graph, and it agrees with the train-mode forward
+    model.eval()
+    with torch.no_grad():
+        y_eval = model(frame)
+    assert not y_eval.requires_grad
+    model.train()
+    y_train = model(frame)
+    assert relerr(y_train.detach().cpu().numpy(), y_eval.cpu().numpy()) < 1e-5
+    with torch.no_grad():
+        assert not model(frame).requires_grad                       # train mode under no_grad: the inference path
+
+
+def test_autograd_boundary_semantics(dev):
+    """Gradient accumulation over two backward calls, frozen parameters, the second-backward error, sum-reduced losses in
+    the split-fp16 mode (the internal power-of-two scaling follows the incoming gradient, not the loss formula)."""
+    from stofnet_amd import StofNet
+    sd = synth.synth_state_dict(4, seed=5)
+    x = torch.from_numpy(synth.synth_echo(3, 320, seed=4)).to(dev)
+
+    def build(tp):
+        m = StofNet(upsample_factor=4, train_precision=tp)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        return m.to(dev).train()
+
+    m = build('fp32')
+    y = m(x)
+    (y ** 2).mean().backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    (m(x) ** 2).mean().backward()                                   # no zero_grad: torch accumulates into .grad
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-6, atol=0), n
+    with pytest.raises(RuntimeError, match='second time'):
+        y.sum().backward()
+    # sum-reduced loss: gradients ~1e6 x larger than the mean-reduced ones; both modes must agree
+    ref = {}
+    for tp in ('fp32', 'f16x3'):
+        mm = build(tp)
+        (mm(x) ** 2).sum().backward()
+        for n, p in mm.named_parameters():
+            if tp == 'fp32':
+                ref[n] = p.grad.clone()
+            else:
+                assert float((p.grad - ref[n]).abs().max()) < 2e-3 * float(ref[n].abs().max()), n
+    with pytest.raises(NotImplementedError):
+        m(x.clone().requires_grad_())
+    for p in m.parameters():
+        p.requires_grad_(False)
+    assert not m(x).requires_grad                                    # nothing to train: plain inference path
+
+
+def test_main_entry_point_trains_through_the_autograd_boundary(dev, tmp_path):
+    """`python main.py evaluate=False trainer=autograd`: torch.optim.AdamW + CosineAnnealingLR + torch loss drive the
+    HIP backward; same loss trajectory as the fused trainer (same seeds, same batches) to fp32 rounding."""
+    import main as entry
+    base = ['model=stofnet', 'evaluate=False', 'epochs=2', 'batch_size=4', 'num_waveforms=24', 'num_samples=400',
+            'th=Null', 'seed=9', 'lr=1e-3']
+    _, s_fused = entry.main(base + [f'ckpt_dir={tmp_path / "a"}', 'run_name=fused-1'])
+    _, s_auto = entry.main(base + [f'ckpt_dir={tmp_path / "b"}', 'run_name=auto-1', 'trainer=autograd'])
+    hf, ha = s_fused['train_history'], s_auto['train_history']
+    assert len(hf) == len(ha) == 2
+    for a, b in zip(hf, ha):
+        assert abs(a['lr'] - b['lr']) < 1e-12
+        assert abs(a['train_loss'] - b['train_loss']) < 2e-3 * abs(a['train_loss'])
+        assert abs(a['val_loss'] - b['val_loss']) < 2e-3 * abs(a['val_loss'])
+    assert ha[-1]['train_loss'] < ha[0]['train_loss']
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
 def test_training_step_at_benched_c5_shape_matches_reference(dev, precision):
     """One reference training step at the shape bench.py --config C5 times (r = 10, L = 2000, seeded weights), batch 8
     (tests/golden/make_golden_r2.py training_c5): loss, predictions, every parameter gradient."""

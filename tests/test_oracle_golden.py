@@ -299,3 +299,59 @@ def test_argmax4096_oracle_subset():
     x = synth.synth_echo(4096, 2000, seed=int(g['seed']))[:48]
     y = so.stofnet_forward(load_weights('different-armadillo'), x, 4, 80).numpy()
     assert np.array_equal(y[:, 0].argmax(-1), g['indices'][:48])
+
+
+# ---------------------------------------------------------------- round 3 fixtures (tests/golden/make_golden_r3.py)
+def test_argmax4096_r10_oracle_subset():
+    g = golden('f1_armadillo_r10_argmax4096')
+    sd = load_weights('different-armadillo')
+    sd['conv_last.weight'], sd['conv_last.bias'] = synth.synth_conv_last(10, seed=int(g['conv_last_seed']))
+    x = synth.synth_echo(4096, 2000, seed=int(g['seed']))[:32]
+    y = so.stofnet_forward(sd, x, 10, 80).numpy()
+    assert np.array_equal(y[:, 0].argmax(-1), g['indices'][:32])
+    top2 = np.sort(y[:, 0], -1)[:, -2:][:, ::-1]
+    assert np.abs(top2 - g['top2'][:32]).max() < 1e-5 * np.abs(g['top2']).max()
+
+
+def sgb_input(n, L, seed):
+    return np.random.default_rng(seed).standard_normal((n, 64, L)).astype(np.float32)
+
+
+@pytest.mark.parametrize('L', [2000, 1536, 160])
+def test_semi_global_block_standalone_oracle(L):
+    """SemiGlobalBlock.forward alone (models/stofnet.py:98-117) with the checkpoint's block."""
+    import torch
+    g = golden('f13_sgb_standalone')
+    sd = load_weights('different-armadillo')
+    y = so.semi_global_block(torch.from_numpy(sgb_input(2, L, 1300 + L)), sd, 'semi_global_block.', 80, torch.float32).numpy()
+    assert np.abs(y[..., ::5] - g[f'y80_L{L}']).max() < 1e-5 * np.abs(g[f'y80_L{L}']).max()
+    assert int(g['err80_L2001']) == 1
+    with pytest.raises(so.OddSemiGlobalRemainder):
+        so.semi_global_block(torch.from_numpy(sgb_input(1, 2001, 1)), sd, 'semi_global_block.', 80, torch.float32)
+
+
+@pytest.mark.parametrize('scale', [40, 20])
+def test_other_semi_global_scales_oracle(scale):
+    """models/stofnet.py:11 accepts any semi_global_scale: feat_scale = scale // 10, pool / upsample by scale."""
+    import torch
+    g = golden('f13_sgb_standalone')
+    sd = synth.synth_state_dict(4, seed=3000 + scale, semi_global_scale=scale)
+    assert sd['semi_global_block.contract_conv.weight'].shape[0] == 64 * (scale // 10)
+    for L in (2000, 1536):
+        y = so.stofnet_forward(sd, synth.synth_echo(2, L, seed=scale + L), 4, scale).numpy()
+        assert np.abs(y - g[f'net{scale}_y_L{L}']).max() < 1e-5 * np.abs(g[f'net{scale}_y_L{L}']).max()
+    yb = so.semi_global_block(torch.from_numpy(sgb_input(2, 1000, 1300 + scale)), sd, 'semi_global_block.', scale, torch.float32).numpy()
+    assert np.abs(yb[..., ::5] - g[f'y{scale}_L1000']).max() < 1e-5 * np.abs(g[f'y{scale}_L1000']).max()
+
+
+def test_pala_gradpeak_oracle_end_to_end():
+    """The PALA GradPeak configuration (main.py:163-164: echo_max inf, peak column; main.py:301 flattening; rf 20) on a
+    synthetic [B, C, S] frame stack: peaks and onsets of the reference."""
+    g = golden('f12_pala_gradpeak')
+    B, C, S, seed = (int(g[k]) for k in ('B', 'C', 'S', 'seed'))
+    x = synth.pala_frames(B, C, S, seed).reshape(-1, 1, S)
+    env = po.hilbert_envelope(x[:, 0])
+    for thn, th in (('1em5', 1e-5), ('1em4', 1e-4)):
+        peaks = po.gradpeak_forward(x, th, 20, float('inf'), False, env=env)
+        onsets = po.gradpeak_forward(x, th, 20, float('inf'), True, env=env)
+        assert np.array_equal(peaks, g[f'peaks_th{thn}']) and np.array_equal(onsets, g[f'onsets_th{thn}'])
