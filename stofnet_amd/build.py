@@ -17,6 +17,9 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libstofnet_amd.so')
 SOURCES = ['pack_weights.cpp', 'convstack.hip', 'shuffle_picker.hip', 'hilbert.hip', 'gradpeak.hip', 'neighbors.hip', 'train.hip']
 ARCH = 'gfx950'
+# convstack.hip: the SLP vectoriser pairs scalar fp32 FMAs into v_pk_fma_f32 (slow beside MFMAs) and thereby defeats the
+# v_fma_mix_f32 selection of the sweep's epilogue (see mix_add in convstack.hip)
+EXTRA_FLAGS = {'convstack.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc() -> str:
@@ -47,7 +50,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if not os.path.exists(path):
             raise RuntimeError(f'listed source {path} is missing: refusing to link a library without its symbols')
         obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
-        cmd = [hipcc, '-O3', '-std=c++17', '-fPIC', '-fconstexpr-steps=100000000', f'--offload-arch={ARCH}', '-x', 'hip', '-c', path, '-o', obj]
+        cmd = [hipcc, '-O3', '-std=c++17', '-fPIC', '-fconstexpr-steps=100000000', f'--offload-arch={ARCH}', '-x', 'hip'] + \
+              EXTRA_FLAGS.get(src, []) + ['-c', path, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -123,6 +123,32 @@ __device__ __forceinline__ float4 load_act4(const char* row, int c0) {
     }
 }
 
+// v + (float)h and v - (float)h as ONE mixed-precision FMA each (v_fma_mix_f32: fp16 source, fp32 arithmetic).  `one` is a
+// 1.0f the optimiser cannot see through (opaque_one()), so the expression stays an FMA with an fpext operand, which the
+// backend selects as v_fma_mix_f32; this file is built with -fno-slp-vectorize because the SLP vectoriser would otherwise pair
+// two of them into v_cvt_f32_f16 x2 + v_pk_fma_f32, and packed-f32 VALU is slow beside MFMAs (MI355X_MICROARCH.md).
+__device__ __forceinline__ float opaque_one() {
+    float one;
+    asm volatile("s_mov_b32 %0, 1.0" : "=s"(one));
+    return one;
+}
+__device__ __forceinline__ float mix_add(_Float16 h, float v, float one) { return __builtin_fmaf((float)h, one, v); }
+__device__ __forceinline__ float mix_sub(_Float16 h, float v, float one) { return __builtin_fmaf(-(float)h, one, v); }
+__device__ __forceinline__ half2v cvt_h2(float a, float b) {
+    const float2v v = {a, b};
+    return __builtin_convertvector(v, half2v);         // v_cvt_pk_f16_f32 (round to nearest even)
+}
+__device__ __forceinline__ unsigned h2_bits(half2v h) {
+    union { half2v h; unsigned u; } c;
+    c.h = h;
+    return c.u;
+}
+__device__ __forceinline__ half2v bits_h2(unsigned u) {
+    union { half2v h; unsigned u; } c;
+    c.u = u;
+    return c.h;
+}
+
 #ifdef STOF_STAMPS
 // diagnostic build: shader-clock stamp with its own wait (cdna_hip_programming.md section 7)
 __device__ __forceinline__ unsigned long long stamp() {
@@ -174,22 +200,31 @@ struct BodyParams {
     int onset_slots, onset_seg_slots;
 };
 
-template <int S, int RING, int RAWRING>
+// RF = floats per activation row: ROWF (272 B) for the 32-wide MFMA shapes; 72 (288 B) for the 16x16x32 body, whose
+// operand reads (lane = (time row i, k-group q), 16 B at 16 q) are bank-conflict free exactly when the row stride is
+// 2 mod 4 in 16-byte units: unit index mod 16 = 2 i + q + const, and the hardware's ds_read_b128 lane groups pair rows
+// {0-3, 12-15} of one q with rows {4-11} of q + 1 (MI355X_MICROARCH.md, LDS table) -- even values against odd ones.
+template <int S, int RING, int RAWRING, int RF = ROWF>
 struct BodyLds {
     static constexpr int X = 0;
-    static constexpr int Y = X + RING * ROWF;
-    static constexpr int RAW = Y + RING * ROWF;
+    static constexpr int Y = X + RING * RF;
+    static constexpr int RAW = Y + RING * RF;
     static constexpr int BIAS = RAW + RAWRING;
     static constexpr int SGL = BIAS + 13 * 64;           // [8 windows][64 ch] SemiGlobalBlock rows
     static constexpr int TOTAL = SGL + 8 * 64;
     static constexpr size_t BYTES = (size_t)TOTAL * sizeof(float);
 };
 
-template <int PREC, int S, int RING, int RAWRING>
+constexpr int ROWF16 = 72;        // 288-byte rows of the 16x16x32 body (see BodyLds)
+
+template <int PREC, int S, int RING, int RAWRING, int SHAPE = 32>
 __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) {
     static_assert((RING & (RING - 1)) == 0 && (RAWRING & (RAWRING - 1)) == 0, "rings are powers of two");
     static_assert(S % 64 == 0 && S + 36 <= RING && S + 42 <= RAWRING, "ring must hold the live span");
-    using Lds = BodyLds<S, RING, RAWRING>;
+    static_assert(SHAPE == 32 || (SHAPE == 16 && PREC == STOF_PREC_F16X3), "the 16x16x32 body is a split-fp16 kernel");
+    constexpr int RF = SHAPE == 16 ? ROWF16 : ROWF;
+    constexpr int ROWB = RF * 4;                 // activation row stride in bytes (shadows the namespace constant)
+    using Lds = BodyLds<S, RING, RAWRING, RF>;
     constexpr int NT = S / 64;                   // N-tiles (32 rows) per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const Xr = reinterpret_cast<char*>(smem + Lds::X);
@@ -249,9 +284,54 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
     // LDS once, rows are decoded incrementally (one division per pass), and every SemiGlobalBlock
     // load is issued before the first FMA so L2 latency is paid once per pass.
     // (nR, tR) = waveform / time of stream row `rstart`, maintained incrementally by the caller
+    const float one_x0 = opaque_one();
     auto x0_pass = [&](char* dst, int rstart, int nR, int tR) {
         constexpr int NIT = S / 16;
         const int g0 = rstart + rl * NIT;
+        // Fast path (work-group uniform test): the pass's S rows lie inside ONE waveform, all of them real samples and (with a
+        // SemiGlobalBlock) inside the up-sampled map -- the common case by far (a waveform is ~10 steps long).  Then no row
+        // needs decoding or masking, and a thread's NIT consecutive rows meet at most two pooling windows, whose rows are
+        // read from LDS once.  The general path below handles waveform boundaries, padding rows and the segment mode.
+        if (!seg_mode && rstart >= 0 && rstart + S <= gend && tR + S <= L &&
+            (p.sgb == nullptr || (tR >= p.rem_half && tR + S - p.rem_half <= SGB_SCALE * p.P))) {
+            float xs[NIT + 8];
+#pragma unroll
+            for (int i = 0; i < NIT + 8; ++i) xs[i] = rawr[(g0 - 4 + i) & (RAWRING - 1)];
+            float4 sgA = make_float4(0.f, 0.f, 0.f, 0.f), sgB = sgA;
+            int sw = NIT;                                   // rows of this thread that belong to its first window
+            if (p.sgb != nullptr) {
+                const int pos0 = tR + rl * NIT - p.rem_half;
+                const int w0 = pos0 / SGB_SCALE;
+                sw = SGB_SCALE * (w0 + 1) - pos0;
+                const int wid = (n0 + nR) * p.P + w0;
+                sgA = ld4(sgl + (wid & 7) * NF + 4 * cq);
+                sgB = ld4(sgl + ((wid + 1) & 7) * NF + 4 * cq);   // staged only if a row of the pass meets it; unused otherwise
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const bool first = it < sw;
+                const float sg[4] = {first ? sgA.x : sgB.x, first ? sgA.y : sgB.y, first ? sgA.z : sgB.z, first ? sgA.w : sgB.w};
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float a = b1[i];
+#pragma unroll
+                    for (int d = 0; d < 9; ++d) a = fmaf(w1[i][d], xs[it + d], a);
+                    v[i] = fmaxf(a, 0.f) + sg[i];
+                }
+                char* const row = dst + ((g0 + it) & (RING - 1)) * ROWB;
+                if constexpr (PREC == STOF_PREC_FP32) {
+                    *reinterpret_cast<float4*>(row + 16 * cq) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    const half2v h01 = cvt_h2(v[0], v[1]), h23 = cvt_h2(v[2], v[3]);
+                    const half2v l01 = cvt_h2(mix_sub(h01[0], v[0], one_x0), mix_sub(h01[1], v[1], one_x0));
+                    const half2v l23 = cvt_h2(mix_sub(h23[0], v[2], one_x0), mix_sub(h23[1], v[3], one_x0));
+                    *reinterpret_cast<uint2*>(row + 8 * cq) = make_uint2(h2_bits(h01), h2_bits(h23));
+                    *reinterpret_cast<uint2*>(row + 128 + 8 * cq) = make_uint2(h2_bits(l01), h2_bits(l23));
+                }
+            }
+            return;
+        }
         int nb, tb;
         decode_row(nR, tR, rl * NIT, nb, tb);
         float xs[NIT + 8];
@@ -384,6 +464,367 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             const char* const src = reads_x ? Xr : Yr;
             const int K = last ? 3 : 7, half = K >> 1;
             const int R0 = F - S - layer_lag(j);
+            // conv_last with r <= 16 on one 16-channel tile (split-fp16 modes): shared by both body shapes
+            auto conv_last16 = [&]() {
+                // conv_last with r <= 16: one 16-channel output tile on v_mfma_f32_16x16x32_f16 instead of two
+                // 32-channel tiles (of which 22+ channels are padding): every wave takes 48 rows of the step,
+                // a quarter of the MFMA work.  D[out-ch][time]: lane (j = lane & 15, q4 = lane >> 4) ends up
+                // with output channels 4 q4 .. 4 q4 + 3 of time row j.
+                const int j16 = lane & 15, q4 = lane >> 4;
+                const uint4* lw = reinterpret_cast<const uint4*>(p.last16) + lane;
+                uint4 wh[BODY_CHUNKS_LAST], wl[BODY_CHUNKS_LAST];
+#pragma unroll
+                for (int cc = 0; cc < BODY_CHUNKS_LAST; ++cc) { wh[cc] = lw[(cc * 2) * 64]; wl[cc] = lw[(cc * 2 + 1) * 64]; }
+#pragma unroll
+                for (int f = 0; f < FRAGS_PER_CHUNK; ++f) { wf[0][f] = wload(0, f); wf[1][f] = wload(1, f); }   // next step
+                const float4 b4 = ld4(biasl + 12 * 64 + 4 * q4);
+                floatx4 a16[3];
+                bool bad = false;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    a16[k][0] = b4.x; a16[k][1] = b4.y; a16[k][2] = b4.z; a16[k][3] = b4.w;
+                    const int off = 48 * wave + 16 * k + j16;
+#pragma unroll
+                    for (int cc = 0; cc < BODY_CHUNKS_LAST; ++cc) {
+                        const int d = cc >> 1, hh = cc & 1;
+                        const char* row = src + ((R0 + off + d - 1) & (RING - 1)) * ROWB + (32 * hh + 8 * q4) * 2;
+                        const half8 bh = as_h8(ldq(row)), bl = as_h8(ldq(row + 128));
+                        a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wh[cc]), bh, a16[k], 0, 0, 0);
+                        a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wh[cc]), bl, a16[k], 0, 0, 0);
+                        a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wl[cc]), bh, a16[k], 0, 0, 0);
+                    }
+                }
+                STAMP_ADD(4);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int off = 48 * wave + 16 * k + j16;
+                    const int g = R0 + off;
+                    int nk, tk, nw, tw;
+                    decode_row(nR, tR, off, nk, tk);
+                    vmap(n0 + nk, tk, nw, tw);
+                    const bool ok = (g >= 0) && (g < gend) && (tk < L) && (tw >= 0) && (tw < Ltrue) &&
+                                    (tk >= p.halo) && (tk < p.halo + p.seg_len);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bad = bad || !(fabsf(a16[k][e]) <= 3.0e38f);
+                    if (p.onset_ws != nullptr) {
+                        // fused arg-max picker: per (virtual) waveform of this tile -- at most two, the tile is 16
+                        // consecutive stream rows -- its max / min and the positions equal to the max
+                        const bool lane_ok = ok && 4 * q4 < r;
+                        float lm = -INFINITY, ll = INFINITY;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (lane_ok && 4 * q4 + e < r) { lm = fmaxf(lm, a16[k][e]); ll = fminf(ll, a16[k][e]); }
+                        const int nv = n0 + nk;
+                        const int nvA = __shfl(nv, 0), nvB = __shfl(nv, 15);
+                        for (int pass = 0; pass < 2; ++pass) {
+                            const int nvX = pass ? nvB : nvA;
+                            if (pass && nvB == nvA) break;
+                            const bool mine = lane_ok && nv == nvX;
+                            const unsigned long long mm = __ballot(mine) & 0xffffull;      // rows of this waveform (q4 = 0 lanes)
+                            if (mm == 0) continue;
+                            float m = mine ? lm : -INFINITY, lo = mine ? ll : INFINITY;
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); lo = fminf(lo, __shfl_xor(lo, o)); }
+                            const int jf = __builtin_ctzll(mm);
+                            const int tw_base = __shfl(tw - j16, jf);
+                            const int nwX = __shfl(nw, jf);
+                            const int seg = nvX & seg_mask;
+                            const int slot = seg * p.onset_seg_slots + (tw_base + jf - seg * p.seg_len + 15) / 16;
+                            unsigned long long eq[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) eq[e] = __ballot(mine && 4 * q4 + e < r && a16[k][e] == m);
+                            if (lane == 0) {
+                                uint4* dst = reinterpret_cast<uint4*>(p.onset_ws + (size_t)nwX * p.onset_slots + slot);
+                                dst[0] = make_uint4(1u, (unsigned)tw_base, __float_as_uint(m), __float_as_uint(lo));
+                                dst[1] = make_uint4((unsigned)eq[0], (unsigned)(eq[0] >> 32), (unsigned)eq[1], (unsigned)(eq[1] >> 32));
+                                dst[2] = make_uint4((unsigned)eq[2], (unsigned)(eq[2] >> 32), (unsigned)eq[3], (unsigned)(eq[3] >> 32));
+                            }
+                        }
+                    }
+                    if (!ok || 4 * q4 >= r || p.y == nullptr) continue;
+                    float* const orow = p.y + ((size_t)nw * Ltrue + tw) * r + 4 * q4;
+                    if ((r & 3) == 0) {
+                        st4(orow, make_float4(a16[k][0], a16[k][1], a16[k][2], a16[k][3]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (4 * q4 + e < r) orow[e] = a16[k][e];
+                    }
+                }
+                if (p.status != nullptr && __any(bad) && lane == 0) atomicOr(p.status, 1);
+                STAMP_ADD(5);
+                __syncthreads();
+                STAMP_ADD(2);
+            };
+            if constexpr (SHAPE == 16) {
+                // ---- split-fp16 layer on v_mfma_f32_16x16x32_f16 (stof_common.h "f16x3 body, 16x16x32").  Wave tile as
+                // before (32 output channels x S/2 rows) = 2 M-tiles x NN N-tiles of 16 rows; one chunk = the whole K = 32
+                // of an MFMA: 4 weight fragments (M-tile x hi | lo) and NN x 2 activation fragments feed 6 NN MFMAs.
+                // Lane (i16 = time row of the N-tile, q4 = k-group / accumulator row group): accumulator element e of
+                // acc[m][n] is output channel 32 mi + 8 q4 + 4 m + e of row R0 + 16 (NN ni + n) + i16.
+                if (last && p.last16 != nullptr) {
+                    conv_last16();
+                    continue;
+                }
+                constexpr int NN = S / 32;
+                const int i16 = lane & 15, q4 = lane >> 4;
+                // the layer's bias enters as the C operand of each accumulator's first MFMA (no 48-register initialisation)
+                floatx4 acc[2][NN], bvec[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const float4 bb = ld4(biasl + j * 64 + 32 * mi + 8 * q4 + 4 * m);
+                    bvec[m][0] = bb.x; bvec[m][1] = bb.y; bvec[m][2] = bb.z; bvec[m][3] = bb.w;
+                }
+                const int rbase = R0 + 16 * NN * ni + i16 - half;          // row of N-tile 0, tap 0
+                const int cbyte = 16 * q4;                                  // k-group q4 = channels 8 q4 .. + 7 of the half
+                auto bload = [&](uint4 (&b)[NN][2], int cc) {
+                    const int d = cc >> 1, hh = cc & 1;
+#pragma unroll
+                    for (int n = 0; n < NN; ++n) {
+                        const char* row = src + ((rbase + 16 * n + d) & (RING - 1)) * ROWB + 64 * hh + cbyte;
+                        b[n][0] = ldq(row);
+                        b[n][1] = ldq(row + 128);
+                    }
+                };
+                auto mfma16 = [](const uint4& a, const uint4& b, floatx4 c) {
+                    return __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(a), as_h8(b), c, 0, 0, 0);
+                };
+                // hi*hi, hi*lo, lo*hi of one M-tile against all N-tiles, two N-tiles interleaved so that consecutive MFMAs
+                // never share an accumulator
+                auto mma_half = [&](const uint4& wh, const uint4& wl, const uint4 (&b)[NN][2], int m, bool first) {
+#pragma unroll
+                    for (int n = 0; n < NN; n += 2) {
+                        acc[m][n] = mfma16(wh, b[n][0], first ? bvec[m] : acc[m][n]);
+                        acc[m][n + 1] = mfma16(wh, b[n + 1][0], first ? bvec[m] : acc[m][n + 1]);
+                        acc[m][n] = mfma16(wh, b[n][1], acc[m][n]);
+                        acc[m][n + 1] = mfma16(wh, b[n + 1][1], acc[m][n + 1]);
+                        acc[m][n] = mfma16(wl, b[n][0], acc[m][n]);
+                        acc[m][n + 1] = mfma16(wl, b[n + 1][0], acc[m][n + 1]);
+                    }
+                };
+                static_assert(NN % 2 == 0, "N-tiles are processed in pairs");
+                // one chunk: M-tile 0 against every N-tile, refill its two weight fragments with those of chunk c+2 at once
+                // (their last use is behind them; the loads then have a whole chunk to land), the same for M-tile 1; the
+                // ds_reads of the NEXT chunk's activation fragments ride behind every third MFMA.  The VMEM groups pin the
+                // refills where they are written: left to itself the scheduler sinks them to just before their use.
+                auto do_chunk = [&](uint4 (&w)[FRAGS_PER_CHUNK], uint4 (&bcur)[NN][2], uint4 (&bnext)[NN][2], int cc) {
+                    const int c2 = (c + 2 >= BODY_NCHUNK) ? c + 2 - BODY_NCHUNK : c + 2;
+                    bload(bnext, cc + 1);          // past the layer's last chunk this reads rows nobody uses
+                    mma_half(w[0], w[1], bcur, 0, cc == 0);
+                    w[0] = wload(c2, 0);
+                    w[1] = wload(c2, 1);
+                    mma_half(w[2], w[3], bcur, 1, cc == 0);
+                    w[2] = wload(c2, 2);
+                    w[3] = wload(c2, 3);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int i = 0; i < NN; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    }
+                    ++c;
+                };
+                uint4 bf0[NN][2], bf1[NN][2];
+                bload(bf0, 0);
+                STAMP_ADD(3);                         // layer setup + first activation fragments
+                char* const dst = (j & 1) ? Yr : Xr;                // odd sweep layers write ring Y
+                const bool inplace = !(j & 1) || (j == 11);         // residual add: conv3,5,..,11 and conv12
+                // validity and LDS slot of the wave's row of N-tile n
+                auto row_of = [&](int n, bool& valid, int& slot, int& nw, int& tw, int& tk) {
+                    const int off = 16 * (NN * ni + n) + i16;
+                    const int g = R0 + off;
+                    int nk;
+                    decode_row(nR, tR, off, nk, tk);
+                    vmap(n0 + nk, tk, nw, tw);
+                    valid = (g >= 0) && (g < gend) && (tk < L) && (tw >= 0) && (tw < Ltrue);
+                    slot = (g & (RING - 1)) * ROWB + (32 * mi + 8 * q4) * 2;
+                };
+                if (!last) {
+                    // ---- main part chunk-major, then the last TAILC chunks tile-major: the epilogue of N-tile n-1 (residual add
+                    // or leaky ReLU, validity, fp16 split, ring store: VALU + LDS work) is issued in the shadow of the MFMAs of
+                    // N-tile n; only the last tile's epilogue stays exposed (1/6 of the layer's output, 1/3 with 32-row tiles).
+#ifndef STOF_TAILC
+#define STOF_TAILC 2
+#endif
+                    constexpr int TAILC = STOF_TAILC, MAINC = BODY_CHUNKS_K7 - TAILC;       // A/B: 0 = no tile-major tail, whole epilogue exposed
+#pragma unroll
+                    for (int cc = 0; cc < MAINC; cc += 2) {
+                        do_chunk(wf[0], bf0, bf1, cc);
+                        do_chunk(wf[1], bf1, bf0, cc + 1);
+                    }
+                    // here: wf[0] / wf[1] = the layer's last two chunks, bf0 = activation fragments of chunk MAINC (all tiles);
+                    // bf1 is free: it takes the fragments of the last chunk, which land while tile 0's first MFMAs run
+                    if (TAILC > 0) bload(bf1, MAINC + 1);
+#ifdef STOF_STAMP_TAIL_AS_EPI
+                    STAMP_ADD(4);                     // diagnostic: the tile-major tail is then counted with the epilogue (slot 5)
+#endif
+                    // MFMA k (0..11) of N-tile n in the tail: hi*hi, hi*lo, lo*hi of both M-tiles, interleaved so that consecutive
+                    // MFMAs never share an accumulator; k < 6 on the second-to-last chunk, k >= 6 on the last one
+                    auto tail_mfma = [&](int n, int k) {
+                        const uint4 (&w)[FRAGS_PER_CHUNK] = k < 6 ? wf[0] : wf[1];
+                        const uint4 (&b)[2] = k < 6 ? bf0[n] : bf1[n];
+                        const int kk = k % 6, m = kk & 1;
+                        acc[m][n] = mfma16(w[2 * m + (kk >= 4 ? 1 : 0)], b[(kk >> 1) == 1 ? 1 : 0], acc[m][n]);
+                    };
+                    const float one = opaque_one();
+                    // The tail exists twice (in-place layers: old value + add; activation layers: leaky ReLU) so that the slices
+                    // carry only the VALU work their layer needs.
+                    auto tail = [&](auto inplace_c) {
+                        constexpr bool INPL = decltype(inplace_c)::value;
+                        struct Epi { int slot; uint4 oh, ol; float v[4]; half2v h01, h23; unsigned hi[4], lo[4]; };
+                        // The epilogue of one N-tile (8 consecutive channels of one row per lane) in 12 slices of <= 4 VALU
+                        // instructions, one behind each MFMA of the NEXT tile:  0: LDS slot + (in-place) loads of the old hi | lo
+                        // images -- issued one tile early, nothing waits for LDS inside a region;  1-5 / 6-10: M-tile 0 / 1:
+                        // accumulator read, residual add (two mixed-precision FMAs per value: + hi, + lo) or leaky ReLU, fp16 split;
+                        // 11: the two 16-byte stores.  Branch-free; rows that are padding are zeroed afterwards (rare).
+                        auto epi_slice = [&](Epi& e, int n, int k) {
+                            if (k == 0) {
+                                e.slot = ((R0 + 16 * (NN * ni + n) + i16) & (RING - 1)) * ROWB + (32 * mi + 8 * q4) * 2;
+                                if constexpr (INPL) { e.oh = ldq(dst + e.slot); e.ol = ldq(dst + e.slot + 128); }
+                                return;
+                            }
+                            if (k == 11) {
+                                *reinterpret_cast<uint4*>(dst + e.slot) = make_uint4(e.hi[0], e.hi[1], e.hi[2], e.hi[3]);
+                                *reinterpret_cast<uint4*>(dst + e.slot + 128) = make_uint4(e.lo[0], e.lo[1], e.lo[2], e.lo[3]);
+                                return;
+                            }
+                            const int m = (k - 1) / 5, st = (k - 1) % 5;
+                            if (st == 0) {
+#pragma unroll
+                                for (int x = 0; x < 4; ++x) e.v[x] = acc[m][n][x];
+                            } else if (st <= 2) {
+                                const int x0 = 2 * (st - 1);                  // values x0, x0 + 1 = one packed pair of the old images
+                                if constexpr (INPL) {
+                                    const unsigned hw = m ? (st == 1 ? e.oh.z : e.oh.w) : (st == 1 ? e.oh.x : e.oh.y);
+                                    const unsigned lw = m ? (st == 1 ? e.ol.z : e.ol.w) : (st == 1 ? e.ol.x : e.ol.y);
+                                    const half2v h = bits_h2(hw), l = bits_h2(lw);
+                                    e.v[x0] = mix_add(l[0], mix_add(h[0], e.v[x0], one), one);
+                                    e.v[x0 + 1] = mix_add(l[1], mix_add(h[1], e.v[x0 + 1], one), one);
+                                } else {
+                                    // leaky_relu(v, 0.01) = max(v, 0.01 v) = med3(v, 0.01 v, huge): one op, where fmaxf costs a canonicalising v_max on top
+                                    e.v[x0] = __builtin_amdgcn_fmed3f(e.v[x0], 0.01f * e.v[x0], 3.0e38f);
+                                    e.v[x0 + 1] = __builtin_amdgcn_fmed3f(e.v[x0 + 1], 0.01f * e.v[x0 + 1], 3.0e38f);
+                                }
+                            } else if (st == 3) {
+                                e.h01 = cvt_h2(e.v[0], e.v[1]);
+                                e.h23 = cvt_h2(e.v[2], e.v[3]);
+                                e.v[0] = mix_sub(e.h01[0], e.v[0], one);
+                                e.v[1] = mix_sub(e.h01[1], e.v[1], one);
+                            } else {
+                                e.v[2] = mix_sub(e.h23[0], e.v[2], one);
+                                e.v[3] = mix_sub(e.h23[1], e.v[3], one);
+                                e.hi[2 * m] = h2_bits(e.h01); e.hi[2 * m + 1] = h2_bits(e.h23);
+                                e.lo[2 * m] = h2_bits(cvt_h2(e.v[0], e.v[1]));
+                                e.lo[2 * m + 1] = h2_bits(cvt_h2(e.v[2], e.v[3]));
+                            }
+                        };
+                        // tile-major over the last two chunks: MFMA k of N-tile n, then slice k of N-tile n-1's epilogue (slice 0: of
+                        // its own); a full scheduling barrier after each pair pins the interleave -- the group-barrier solver clumps
+                        // the VALU work when given this mix
+                        Epi ep[2];
+                        if constexpr (TAILC == 0) {
+#pragma unroll
+                            for (int n = 0; n < NN; ++n) {
+#pragma unroll
+                                for (int k = 0; k < 12; ++k) epi_slice(ep[0], n, k);
+                            }
+                            return;
+                        }
+#pragma unroll
+                        for (int n = 0; n < NN; ++n) {
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) {
+                                tail_mfma(n, k);
+                                if (k == 0) epi_slice(ep[n & 1], n, 0);
+                                else if (n > 0) epi_slice(ep[(n - 1) & 1], n - 1, k);
+                                if (n == NN - 1 && (k == 5 || k == 11)) {   // last use of wf[0] / wf[1]: refill with the next layer's first chunks
+                                    const int q = k == 5 ? 0 : 1;
+                                    const int c2 = (c + 2 + q >= BODY_NCHUNK) ? c + 2 + q - BODY_NCHUNK : c + 2 + q;
+#pragma unroll
+                                    for (int f = 0; f < FRAGS_PER_CHUNK; ++f) wf[q][f] = wload(c2, f);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        c += TAILC;
+#ifdef STOF_STAMP_TAIL_AS_EPI
+                        STAMP_ADD(5);
+#else
+                        STAMP_ADD(4);                     // chunk loop (MFMA) incl. the overlapped epilogues
+#endif
+#pragma unroll
+                        for (int k = 1; k < 12; ++k) epi_slice(ep[(NN - 1) & 1], NN - 1, k);
+                    };
+                    if (inplace) tail(std::true_type{});
+                    else tail(std::false_type{});
+                    // Rows outside [0, L) of their waveform (gap rows, stream ends, segment padding) must read as zeros for the
+                    // next layer (= its zero padding).  Wave-uniform test on the wave's S/2-row span: when the whole span lies
+                    // inside one waveform nothing is to do (the common case); otherwise the lanes of padding rows overwrite
+                    // what the branch-free tail stored (same lane, program order: no race; the barrier follows).
+                    {
+                        const int offw = 16 * NN * ni, g0 = R0 + offw;
+                        int nk0, tk0, nw0, tw0;
+                        decode_row(nR, tR, offw, nk0, tk0);
+                        vmap(n0 + nk0, tk0, nw0, tw0);
+                        const bool span_ok = (g0 >= 0) && (g0 + 16 * NN - 1 < gend) && (tk0 + 16 * NN - 1 < L) && (tw0 >= 0) &&
+                                             (tw0 + 16 * NN - 1 < Ltrue);
+                        if (!span_ok) {
+#pragma unroll 1
+                            for (int n = 0; n < NN; ++n) {
+                                bool valid;
+                                int slot, nw, tw, tk;
+                                row_of(n, valid, slot, nw, tw, tk);
+                                if (!valid) {
+                                    *reinterpret_cast<uint4*>(dst + slot) = make_uint4(0u, 0u, 0u, 0u);
+                                    *reinterpret_cast<uint4*>(dst + slot + 128) = make_uint4(0u, 0u, 0u, 0u);
+                                }
+                            }
+                        }
+                    }
+                    STAMP_ADD(5);                     // exposed epilogue (last tile)
+                    __syncthreads();
+                    STAMP_ADD(2);
+                    continue;
+                }
+                // ---- conv_last with r > 16 (the 16-channel tile of conv_last16 serves r <= 16): 6 chunks, outputs to HBM
+#pragma unroll
+                for (int cc = 0; cc < BODY_CHUNKS_LAST; cc += 2) { do_chunk(wf[0], bf0, bf1, cc); do_chunk(wf[1], bf1, bf0, cc + 1); }
+                STAMP_ADD(4);                         // chunk loop (MFMA)
+                bool bad = false;
+#pragma unroll
+                for (int n = 0; n < NN; ++n) {
+                    bool valid;
+                    int slot, nw, tw, tk;
+                    row_of(n, valid, slot, nw, tw, tk);
+                    // conv_last + SampleShuffle1D: out[n][t*r + k] = conv_last[n][k][t]; only the segment's own rows
+                    valid = valid && (tk >= p.halo) && (tk < p.halo + p.seg_len);
+                    const float v[8] = {acc[0][n][0], acc[0][n][1], acc[0][n][2], acc[0][n][3],
+                                        acc[1][n][0], acc[1][n][1], acc[1][n][2], acc[1][n][3]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bad = bad || !(fabsf(v[e]) <= 3.0e38f);
+                    if (!valid || p.y == nullptr) continue;
+                    float* const orow = p.y + ((size_t)nw * Ltrue + tw) * r;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int c0 = 32 * mi + 8 * q4 + 4 * m;
+                        if (c0 >= r) continue;
+                        if ((r & 3) == 0) {
+                            st4(orow + c0, make_float4(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (c0 + e < r) orow[c0 + e] = v[4 * m + e];
+                        }
+                    }
+                }
+                if (p.status != nullptr && __any(bad) && lane == 0) atomicOr(p.status, 1);
+                STAMP_ADD(5);                         // epilogue
+                __syncthreads();
+                STAMP_ADD(2);
+            } else {
             // (for conv_last with r <= 32 the waves of the upper output tile multiply zero-padded
             //  weights: free in wall time, and it keeps the chunk body branch-free)
             // accumulators start at the layer's bias (lane (ln, lh) holds channels 32mi + 8gg + 4lh + e)
@@ -607,95 +1048,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             }
             if constexpr (PREC == STOF_PREC_F16X3) {
                 if (p.last16 != nullptr) {
-                    // conv_last with r <= 16: one 16-channel output tile on v_mfma_f32_16x16x32_f16 instead of two
-                    // 32-channel tiles (of which 22+ channels are padding): every wave takes 48 rows of the step,
-                    // a quarter of the MFMA work.  D[out-ch][time]: lane (j = lane & 15, q4 = lane >> 4) ends up
-                    // with output channels 4 q4 .. 4 q4 + 3 of time row j.
-                    const int j16 = lane & 15, q4 = lane >> 4;
-                    const uint4* lw = reinterpret_cast<const uint4*>(p.last16) + lane;
-                    uint4 wh[BODY_CHUNKS_LAST], wl[BODY_CHUNKS_LAST];
-#pragma unroll
-                    for (int cc = 0; cc < BODY_CHUNKS_LAST; ++cc) { wh[cc] = lw[(cc * 2) * 64]; wl[cc] = lw[(cc * 2 + 1) * 64]; }
-#pragma unroll
-                    for (int f = 0; f < FRAGS_PER_CHUNK; ++f) { wf[0][f] = wload(0, f); wf[1][f] = wload(1, f); }   // next step
-                    const float4 b4 = ld4(biasl + 12 * 64 + 4 * q4);
-                    floatx4 a16[3];
-                    bool bad = false;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        a16[k][0] = b4.x; a16[k][1] = b4.y; a16[k][2] = b4.z; a16[k][3] = b4.w;
-                        const int off = 48 * wave + 16 * k + j16;
-#pragma unroll
-                        for (int cc = 0; cc < BODY_CHUNKS_LAST; ++cc) {
-                            const int d = cc >> 1, hh = cc & 1;
-                            const char* row = src + ((R0 + off + d - 1) & (RING - 1)) * ROWB + (32 * hh + 8 * q4) * 2;
-                            const half8 bh = as_h8(ldq(row)), bl = as_h8(ldq(row + 128));
-                            a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wh[cc]), bh, a16[k], 0, 0, 0);
-                            a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wh[cc]), bl, a16[k], 0, 0, 0);
-                            a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wl[cc]), bh, a16[k], 0, 0, 0);
-                        }
-                    }
-                    STAMP_ADD(4);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int off = 48 * wave + 16 * k + j16;
-                        const int g = R0 + off;
-                        int nk, tk, nw, tw;
-                        decode_row(nR, tR, off, nk, tk);
-                        vmap(n0 + nk, tk, nw, tw);
-                        const bool ok = (g >= 0) && (g < gend) && (tk < L) && (tw >= 0) && (tw < Ltrue) &&
-                                        (tk >= p.halo) && (tk < p.halo + p.seg_len);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) bad = bad || !(fabsf(a16[k][e]) <= 3.0e38f);
-                        if (p.onset_ws != nullptr) {
-                            // fused arg-max picker: per (virtual) waveform of this tile -- at most two, the tile is 16
-                            // consecutive stream rows -- its max / min and the positions equal to the max
-                            const bool lane_ok = ok && 4 * q4 < r;
-                            float lm = -INFINITY, ll = INFINITY;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (lane_ok && 4 * q4 + e < r) { lm = fmaxf(lm, a16[k][e]); ll = fminf(ll, a16[k][e]); }
-                            const int nv = n0 + nk;
-                            const int nvA = __shfl(nv, 0), nvB = __shfl(nv, 15);
-                            for (int pass = 0; pass < 2; ++pass) {
-                                const int nvX = pass ? nvB : nvA;
-                                if (pass && nvB == nvA) break;
-                                const bool mine = lane_ok && nv == nvX;
-                                const unsigned long long mm = __ballot(mine) & 0xffffull;      // rows of this waveform (q4 = 0 lanes)
-                                if (mm == 0) continue;
-                                float m = mine ? lm : -INFINITY, lo = mine ? ll : INFINITY;
-#pragma unroll
-                                for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); lo = fminf(lo, __shfl_xor(lo, o)); }
-                                const int jf = __builtin_ctzll(mm);
-                                const int tw_base = __shfl(tw - j16, jf);
-                                const int nwX = __shfl(nw, jf);
-                                const int seg = nvX & seg_mask;
-                                const int slot = seg * p.onset_seg_slots + (tw_base + jf - seg * p.seg_len + 15) / 16;
-                                unsigned long long eq[4];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) eq[e] = __ballot(mine && 4 * q4 + e < r && a16[k][e] == m);
-                                if (lane == 0) {
-                                    uint4* dst = reinterpret_cast<uint4*>(p.onset_ws + (size_t)nwX * p.onset_slots + slot);
-                                    dst[0] = make_uint4(1u, (unsigned)tw_base, __float_as_uint(m), __float_as_uint(lo));
-                                    dst[1] = make_uint4((unsigned)eq[0], (unsigned)(eq[0] >> 32), (unsigned)eq[1], (unsigned)(eq[1] >> 32));
-                                    dst[2] = make_uint4((unsigned)eq[2], (unsigned)(eq[2] >> 32), (unsigned)eq[3], (unsigned)(eq[3] >> 32));
-                                }
-                            }
-                        }
-                        if (!ok || 4 * q4 >= r || p.y == nullptr) continue;
-                        float* const orow = p.y + ((size_t)nw * Ltrue + tw) * r + 4 * q4;
-                        if ((r & 3) == 0) {
-                            st4(orow, make_float4(a16[k][0], a16[k][1], a16[k][2], a16[k][3]));
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (4 * q4 + e < r) orow[e] = a16[k][e];
-                        }
-                    }
-                    if (p.status != nullptr && __any(bad) && lane == 0) atomicOr(p.status, 1);
-                    STAMP_ADD(5);
-                    __syncthreads();
-                    STAMP_ADD(2);
+                    conv_last16();
                     continue;
                 }
             }
@@ -813,6 +1166,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             STAMP_ADD(5);                         // epilogue
             __syncthreads();
             STAMP_ADD(2);
+            }   // SHAPE == 32
         }
     }
 #ifdef STOF_STAMPS
@@ -1073,10 +1427,18 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
     const float* ew = base + off;      off += 5ull * NF_SGB * NF;
     const float* ebias = base + off;
 
+    // split-fp16 body: 16x16x32 MFMA form unless STOF_BODY16=0 (the packed blob carries the matching fragment order)
+    static const bool body16 = PREC == STOF_PREC_F16X3 && body16_enabled();
+    constexpr int SHAPE_FAST = PREC == STOF_PREC_F16X3 ? 16 : 32;
     using Lds = BodyLds<BODY_S, BODY_RING, BODY_RAWRING>;
-    static LdsLimitOnce body_lds, sgb_lds;                 // one per template instantiation (PREC)
-    if (int st = body_lds.ensure(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>),
-                                 (int)Lds::BYTES)) return st;
+    using Lds16 = BodyLds<BODY_S, BODY_RING, BODY_RAWRING, ROWF16>;
+    const size_t body_lds_bytes = body16 ? Lds16::BYTES : Lds::BYTES;
+    static LdsLimitOnce body_lds, body16_lds, sgb_lds;     // one per template instantiation (PREC)
+    if (body16) {
+        if (int st = body16_lds.ensure(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING, SHAPE_FAST>),
+                                       (int)Lds16::BYTES)) return st;
+    } else if (int st = body_lds.ensure(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>),
+                                        (int)Lds::BYTES)) return st;
     if (int st = sgb_lds.ensure(reinterpret_cast<const void*>(&sgb_contract_pool_kernel<PREC, SGB_NW>), (int)sgb_lds_bytes()))
         return st;
     const int ncu = device_cu_count();
@@ -1156,8 +1518,12 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         int64_t wgs = nv < ncu ? nv : ncu;
         bp.wf_per_wg = (int)((nv + wgs - 1) / wgs);
         wgs = (nv + bp.wf_per_wg - 1) / bp.wf_per_wg;
-        hipLaunchKernelGGL((body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>), dim3((unsigned)wgs), dim3(256),
-                           Lds::BYTES, stream, bp);
+        if (body16)
+            hipLaunchKernelGGL((body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING, SHAPE_FAST>), dim3((unsigned)wgs), dim3(256),
+                               body_lds_bytes, stream, bp);
+        else
+            hipLaunchKernelGGL((body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>), dim3((unsigned)wgs), dim3(256),
+                               body_lds_bytes, stream, bp);
         if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[3]), stream);
         if (onsets != nullptr)
             hipLaunchKernelGGL(onsets_finalize_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, stream, onsets->ws,

@@ -1,5 +1,6 @@
 // Host-side repack of the reference's state_dict (models/stofnet.py:23-31,88,94) into
 // the streaming layout the gfx950 kernels read.  Pure CPU code: no HIP calls.
+#include <stdlib.h>
 #include <string.h>
 #include "stof_common.h"
 
@@ -12,6 +13,7 @@ static void layout(const stof_net_desc* d, PackedHeader* h) {
     h->r = d->upsample_factor;
     h->sgs = d->semi_global_scale;
     h->precision = d->precision;
+    h->pad0 = (d->precision == STOF_PREC_F16X3 && body16_enabled()) ? 1 : 0;     // body chunk layout: 1 = 16x16x32 fragments
     uint64_t off = sizeof(PackedHeader) / sizeof(float);
     h->off_c1 = off;      off += 64 * 10;
     h->off_bias = off;    off += 13 * 64;
@@ -62,6 +64,24 @@ static void pack_chunk(float* dst, int tiles, int row0, const float* w, int co, 
             }
 }
 
+// Body chunk of the split-fp16 sweep on v_mfma_f32_16x16x32_f16 (stof_common.h, "f16x3 body, 16x16x32"): 2 output blocks
+// of 32 channels x 4 fragments (M-tile m = 0, 1 x hi | lo), float offset ((frag * 2 + block) * 64 + lane) * 4.
+static void pack_chunk16(float* dst, const float* w, int co, int ci, int K, int tap, int hh) {
+    for (int frag = 0; frag < FRAGS_PER_CHUNK; ++frag)
+        for (int blk = 0; blk < 2; ++blk)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = frag >> 1, part = frag & 1, i = lane & 15, q = lane >> 4;
+                const int o = body16_out_channel(blk, m, i);
+                _Float16* oh = reinterpret_cast<_Float16*>(dst + ((size_t)(frag * 2 + blk) * 64 + lane) * 4);
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 32 * hh + 8 * q + e;
+                    const float v = o < co ? w[((size_t)o * ci + c) * K + tap] : 0.f;
+                    const _Float16 hi = (_Float16)v;
+                    oh[e] = part == 0 ? hi : (_Float16)(v - (float)hi);
+                }
+            }
+}
+
 extern "C" size_t stof_packed_weights_bytes(const stof_net_desc* desc) {
     if (check_desc(desc) != STOF_OK) return 0;
     PackedHeader h;
@@ -104,7 +124,8 @@ extern "C" int stof_pack_weights(const stof_net_desc* desc, const float* const* 
         const int co = last ? r : NF;
         for (int t = 0; t < K; ++t)
             for (int hh = 0; hh < 2; ++hh) {
-                pack_chunk(ck, 2, 0, w, co, NF, K, t, hh, desc->precision);
+                if (desc->precision == STOF_PREC_F16X3 && body16_enabled()) pack_chunk16(ck, w, co, NF, K, t, hh);
+                else pack_chunk(ck, 2, 0, w, co, NF, K, t, hh, desc->precision);
                 ck += BODY_CHUNK_F;
             }
     }

@@ -2,6 +2,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/stofnet_amd.h"
 
 namespace stof {
@@ -25,6 +26,13 @@ constexpr int ROWF = 68;
 //   fp32  : fragment q (0..3)        : lane (m = l&31, h = l>>5) -> W[m][32*half + 8q + 4h + 0..3]   (4 x fp32)
 //   f16x3 : fragment 2*ks + part     : lane (m, h) -> part(W[m][32*half + 16ks + 8h + 0..7])         (8 x fp16)
 //           part 0 = hi, 1 = lo
+//   f16x3 body, 16x16x32 (r3, the default; STOF_BODY16=0 in the environment of BOTH the packing and the launching process selects
+//           the 32x32x16 form above for A/B runs): the body sweep multiplies on v_mfma_f32_16x16x32_f16 -- on this part the
+//           16x16x32 shape sustains a ~12 % higher clock than 32x32x16 under the power cap at equal cycles per flop
+//           (tools/micro/mfma_shape_lds.hip, profiles/r03_mfma_shape_lds.jsonl).  A chunk is the whole K = 32 of one MFMA:
+//           fragment 2*m + part : lane (i = l&15, q = l>>4) -> part(W[body16_out_channel(block, m, i)][32*half + 8q + 0..7])
+//           The output-channel order inside a 32-channel block is permuted so that the accumulator lane (column = time row,
+//           q) of M-tiles m = 0, 1 holds the 8 CONSECUTIVE channels 8q .. 8q+7: one 16-byte LDS store per lane and row.
 constexpr int FRAGS_PER_CHUNK = 4;
 constexpr int FRAG_F = 256;                                   // floats per fragment (1 KiB)
 constexpr int BODY_CHUNK_F = FRAGS_PER_CHUNK * 2 * FRAG_F;    // 2 output tiles (64 channels)
@@ -55,6 +63,14 @@ struct PackedHeader {
 };
 static_assert(sizeof(PackedHeader) == 256, "header must be 256 bytes");
 constexpr uint32_t PACK_MAGIC = 0x464F5453u;
+
+// 16x16x32 body: output channel held by row i (0..15) of M-tile m (0, 1) of the 32-channel block `block`:
+// accumulator element e of lane (col, q) is row 4q + e, i.e. channel 32 block + 8q + 4m + e.
+inline int body16_out_channel(int block, int m, int i) { return 32 * block + 8 * (i >> 2) + 4 * m + (i & 3); }
+inline bool body16_enabled() {
+    const char* e = getenv("STOF_BODY16");
+    return e == nullptr || e[0] != '0';
+}
 constexpr int LAST16_F = 6 * 2 * 64 * 4;      // floats of the off_last16 section
 
 }  // namespace stof

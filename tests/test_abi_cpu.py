@@ -71,6 +71,21 @@ def unpack_chunk(chunk, tiles, prec):
     return out
 
 
+def unpack_chunk16(chunk):
+    """Body chunk of the split-fp16 sweep on v_mfma_f32_16x16x32_f16 (stof_common.h): [4 frags = (M-tile m, hi | lo)][2 blocks]
+    [64 lanes = (i, q)][8 fp16] -> dense [64 out-channels][32 channels]; row i of M-tile m of block b is output channel
+    32 b + 8 (i >> 2) + 4 m + (i & 3), lane q holds input channels 8 q .. 8 q + 7."""
+    halves = chunk.view(np.float16).reshape(4, 2, 64, 8).astype(np.float64)
+    out = np.zeros((64, 32), np.float64)
+    for m in range(2):
+        for blk in range(2):
+            for lane in range(64):
+                i, q = lane & 15, lane >> 4
+                o = 32 * blk + 8 * (i >> 2) + 4 * m + (i & 3)
+                out[o, 8 * q:8 * q + 8] = halves[2 * m, blk, lane] + halves[2 * m + 1, blk, lane]
+    return out
+
+
 @pytest.mark.parametrize('r,sgs,prec', [(4, 80, 0), (10, 80, 0), (4, 1, 0), (10, 80, 1), (20, 1, 1)])
 def test_pack_layout(lib, r, sgs, prec):
     sd = synth.synth_state_dict(r, seed=1, semi_global_scale=sgs)
@@ -83,6 +98,8 @@ def test_pack_layout(lib, r, sgs, prec):
         return bool(np.all(np.abs(dense - ref) <= np.maximum(2.0 ** -21 * np.abs(ref), 2.0 ** -25)))
     hdr = f[:64].view(np.uint32)
     assert hdr[0] == 0x464F5453 and int(hdr[2].view(np.int32)) == r and int(hdr[4].view(np.int32)) == prec
+    body16 = int(hdr[5]) == 1                  # header word pad0: body chunks in 16x16x32 fragment order (split-fp16, the default)
+    assert body16 == (prec == 1 and os.environ.get('STOF_BODY16', '1') != '0')
     off = 64
     c1 = f[off:off + 640].reshape(64, 10); off += 640
     assert np.array_equal(c1[:, :9], sd['conv1.weight'][:, 0, :]) and np.array_equal(c1[:, 9], sd['conv1.bias'])
@@ -96,7 +113,7 @@ def test_pack_layout(lib, r, sgs, prec):
         w = sd['conv_last.weight'] if j == 12 else sd[f'conv{j + 1}.weight']
         for t in range(w.shape[2]):
             for hh in range(2):
-                dense = unpack_chunk(chunks[c], 2, prec)
+                dense = unpack_chunk16(chunks[c]) if body16 else unpack_chunk(chunks[c], 2, prec)
                 ref = np.zeros((64, 32))
                 ref[:w.shape[0]] = w[:, 32 * hh:32 * hh + 32, t]
                 assert close(dense, ref)
