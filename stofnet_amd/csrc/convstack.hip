@@ -691,6 +691,10 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                                 *reinterpret_cast<uint4*>(dst + e.slot + 128) = make_uint4(e.lo[0], e.lo[1], e.lo[2], e.lo[3]);
                                 return;
                             }
+#ifdef STOF_TAIL_SKIP_VALU
+                            if (k == 1) for (int x = 0; x < 4; ++x) { e.hi[x] = 0u; e.lo[x] = 0u; }      // timing experiment only: wrong results
+                            return;
+#endif
                             const int m = (k - 1) / 5, st = (k - 1) % 5;
                             if (st == 0) {
 #pragma unroll
@@ -722,8 +726,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                             }
                         };
                         // tile-major over the last two chunks: MFMA k of N-tile n, then slice k of N-tile n-1's epilogue (slice 0: of
-                        // its own); a full scheduling barrier after each pair pins the interleave -- the group-barrier solver clumps
-                        // the VALU work when given this mix
+                        // its own) in program order; one scheduling region per tile with (1 MFMA, 4 VALU) groups.  (Given the
+                        // epilogue as four coarse pieces the group-barrier solver clumped the VALU work between two MFMAs.)
                         Epi ep[2];
                         if constexpr (TAILC == 0) {
 #pragma unroll
@@ -746,8 +750,18 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
 #pragma unroll
                                     for (int f = 0; f < FRAGS_PER_CHUNK; ++f) wf[q][f] = wload(c2, f);
                                 }
-                                __builtin_amdgcn_sched_barrier(0);
+#ifdef STOF_TAIL_BLOCK_SCHED
+                                __builtin_amdgcn_sched_barrier(0);      // A/B: pin every (MFMA, slice) pair; measured 0.5 % slower
+#endif
                             }
+#ifndef STOF_TAIL_BLOCK_SCHED
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#endif
                         }
                         c += TAILC;
 #ifdef STOF_STAMP_TAIL_AS_EPI
@@ -1194,16 +1208,19 @@ struct SgbParams {
     const int* run_if;     // as BodyParams::run_if
 };
 
-template <int PREC, int NW>
+template <int PREC, int NW, int SHAPE = 32>
 __global__ __launch_bounds__(256, SGB_WAVES_PER_SIMD) void sgb_contract_pool_kernel(const SgbParams p) {
     static_assert(NW % 2 == 0, "80*NW must be a multiple of 32");
+    static_assert(SHAPE == 32 || (SHAPE == 16 && PREC == STOF_PREC_F16X3), "the 16x16x32 form is a split-fp16 kernel");
     constexpr int ROWS = SGB_SCALE * NW;          // output rows of the tile
     constexpr int MT = ROWS / 32;
     constexpr int TR = ROWS + 4;                  // conv1 rows needed (k5: +-2)
     constexpr int RAWN = TR + 8;                  // raw samples needed (k9: +-4)
+    constexpr int RF = SHAPE == 16 ? ROWF16 : ROWF;           // 288-byte rows for the 16x16x32 operand reads (see BodyLds)
+    constexpr int ROWB = RF * 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const act = reinterpret_cast<char*>(smem);          // [TR] rows of ROWB bytes
-    float* const raw = smem + TR * ROWF;                       // [RAWN]
+    float* const raw = smem + TR * RF;                         // [RAWN]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1255,6 +1272,97 @@ __global__ __launch_bounds__(256, SGB_WAVES_PER_SIMD) void sgb_contract_pool_ker
     __syncthreads();
 
     int c = 0;
+    if constexpr (SHAPE == 16) {
+        // ---- split-fp16 on v_mfma_f32_16x16x32_f16 (stof_common.h "f16x3 SemiGlobalBlock chunks, 16x16x32").  Time stays on
+        // the M axis: D[time 4q+e][channel j] of lane (j = lane & 15, q = lane >> 4), the wave's 32 channels are 2 N-tiles,
+        // the 80 NW rows are 5 NW M-tiles of 16 -- a pooling window is exactly 5 M-tiles, so the pool is an in-lane max
+        // over accumulator registers plus two cross-lane steps (q).  Pipeline unit = the 5 M-tiles of one window against a
+        // whole chunk (K = 32): 10 activation fragments from LDS, 30 MFMAs.
+        constexpr int MW = SGB_SCALE / 16;                        // M-tiles per pooling window
+        const int j16 = lane & 15, q4 = lane >> 4;
+        for (int ocb = 0; ocb < 4; ++ocb) {
+            floatx4 acc[NW][MW][2];
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int m = 0; m < MW; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[w][m][nt][e] = 0.f;
+            constexpr int NUNIT = 10 * NW;                        // 10 chunks (5 taps x 2 halves) x NW windows per output block
+            auto aload = [&](uint4 (&a)[MW][2], int uu) {
+                const int cc = uu / NW, w = uu % NW;
+                const int d = cc >> 1, hh = cc & 1;
+                const char* arow = act + (SGB_SCALE * w + j16 + d) * ROWB + 64 * hh + 16 * q4;
+#pragma unroll
+                for (int m = 0; m < MW; ++m) {
+                    a[m][0] = ldq(arow + 16 * m * ROWB);
+                    a[m][1] = ldq(arow + 16 * m * ROWB + 128);
+                }
+            };
+            auto mfma16 = [](const uint4& a, const uint4& b, floatx4 cacc) {
+                return __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(a), as_h8(b), cacc, 0, 0, 0);
+            };
+            auto do_unit = [&](uint4 (&acur)[MW][2], uint4 (&anext)[MW][2], int uu) {
+                const int cc = uu / NW, w = uu % NW;
+                uint4 (&wq)[FRAGS_PER_CHUNK] = wf[cc & 1];               // fragments: N-tile 0 hi, lo, N-tile 1 hi, lo
+                const int c2 = (c + 2 < SGB_NCHUNK) ? c + 2 : 0;          // past the end: harmless reload of chunk 0
+                aload(anext, uu + 1 < NUNIT ? uu + 1 : 0);               // the next output block starts with the same rows
+#pragma unroll
+                for (int m = 0; m < MW; ++m) {
+                    // hi*hi, lo*hi, hi*lo for both N-tiles, interleaved so that consecutive MFMAs never share an accumulator
+                    acc[w][m][0] = mfma16(acur[m][0], wq[0], acc[w][m][0]);
+                    acc[w][m][1] = mfma16(acur[m][0], wq[2], acc[w][m][1]);
+                    acc[w][m][0] = mfma16(acur[m][1], wq[0], acc[w][m][0]);
+                    acc[w][m][1] = mfma16(acur[m][1], wq[2], acc[w][m][1]);
+                    acc[w][m][0] = mfma16(acur[m][0], wq[1], acc[w][m][0]);
+                    acc[w][m][1] = mfma16(acur[m][0], wq[3], acc[w][m][1]);
+                }
+                if (w == NW - 1) {
+#pragma unroll
+                    for (int f = 0; f < FRAGS_PER_CHUNK; ++f) wq[f] = wload(c2, f);
+                    ++c;
+                }
+#pragma unroll
+                for (int i = 0; i < MW * 2; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if (w == NW - 1) __builtin_amdgcn_sched_group_barrier(0x020, FRAGS_PER_CHUNK, 0);
+                __builtin_amdgcn_sched_barrier(0);      // one scheduling region per unit
+            };
+            uint4 af0[MW][2], af1[MW][2];
+            if (ocb == 0) aload(af0, 0);
+            static_assert(NUNIT % 2 == 0, "units alternate between two fragment sets");
+#pragma unroll
+            for (int uu = 0; uu < NUNIT; uu += 2) {
+                do_unit(af0, af1, uu);
+                do_unit(af1, af0, uu + 1);
+            }
+            // pool: window w = M-tiles of acc[w]; lane (j16, q4) holds time rows 4 q4 + e of every M-tile for channel j16 of each N-tile
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int oc = 128 * ocb + 32 * wave + 16 * nt + j16;
+                const float bias = p.cbias[oc];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    float mval = -INFINITY;
+#pragma unroll
+                    for (int m = 0; m < MW; ++m)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) mval = fmaxf(mval, acc[w][m][nt][e]);
+                    mval = fmaxf(mval, __shfl_xor(mval, 16));
+                    mval = fmaxf(mval, __shfl_xor(mval, 32));
+                    mval += bias;
+                    mval = mval > 0.f ? mval : 0.01f * mval;
+                    if (q4 == 0 && w0 + w < p.P)
+                        p.pooled[((size_t)n * p.P + w0 + w) * NF_SGB + oc] = mval;
+                }
+            }
+        }
+        return;
+    }
     for (int ocb = 0; ocb < 4; ++ocb) {
         floatx16 acc[MT];
 #pragma unroll
@@ -1398,8 +1506,8 @@ struct OnsetArgs {                        // non-null ws: stof_forward_onsets
 };
 constexpr int64_t SUB_BATCH = 4096;      // rows whose SGB maps share one workspace
 
-constexpr size_t sgb_lds_bytes() {
-    return (size_t)((SGB_SCALE * SGB_NW + 4) * ROWF + SGB_SCALE * SGB_NW + 12) * sizeof(float);
+constexpr size_t sgb_lds_bytes(int rowf = ROWF) {
+    return (size_t)((SGB_SCALE * SGB_NW + 4) * rowf + SGB_SCALE * SGB_NW + 12) * sizeof(float);
 }
 
 template <int PREC>
@@ -1439,7 +1547,13 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
                                        (int)Lds16::BYTES)) return st;
     } else if (int st = body_lds.ensure(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>),
                                         (int)Lds::BYTES)) return st;
-    if (int st = sgb_lds.ensure(reinterpret_cast<const void*>(&sgb_contract_pool_kernel<PREC, SGB_NW>), (int)sgb_lds_bytes()))
+    // the SemiGlobalBlock contract kernel follows the body's MFMA shape (and the blob its fragment order)
+    static LdsLimitOnce sgb16_lds;
+    const size_t sgb_bytes = body16 ? sgb_lds_bytes(ROWF16) : sgb_lds_bytes();
+    if (body16) {
+        if (int st = sgb16_lds.ensure(reinterpret_cast<const void*>(&sgb_contract_pool_kernel<PREC, SGB_NW, SHAPE_FAST>), (int)sgb_bytes))
+            return st;
+    } else if (int st = sgb_lds.ensure(reinterpret_cast<const void*>(&sgb_contract_pool_kernel<PREC, SGB_NW>), (int)sgb_bytes))
         return st;
     const int ncu = device_cu_count();
 
@@ -1459,8 +1573,12 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
             sp.N = (int)nb; sp.L = (int)L; sp.P = (int)P;
             sp.tiles_per_wf = (int)((P + SGB_NW - 1) / SGB_NW);
             sp.run_if = run_if;
-            hipLaunchKernelGGL((sgb_contract_pool_kernel<PREC, SGB_NW>), dim3((unsigned)(nb * sp.tiles_per_wf)),
-                               dim3(256), sgb_lds_bytes(), stream, sp);
+            if (body16)
+                hipLaunchKernelGGL((sgb_contract_pool_kernel<PREC, SGB_NW, SHAPE_FAST>), dim3((unsigned)(nb * sp.tiles_per_wf)),
+                                   dim3(256), sgb_bytes, stream, sp);
+            else
+                hipLaunchKernelGGL((sgb_contract_pool_kernel<PREC, SGB_NW>), dim3((unsigned)(nb * sp.tiles_per_wf)),
+                                   dim3(256), sgb_bytes, stream, sp);
             if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(events[1]), stream);
             {
                 const int st = stof::launch_conv_cl(pooled, ew, ebias, nullptr, nullptr, sgb, 1, nb * (P + 2), NF_SGB, NF, 5,

@@ -82,6 +82,24 @@ static void pack_chunk16(float* dst, const float* w, int co, int ci, int K, int 
             }
 }
 
+// SemiGlobalBlock contract chunk for the 16x16x32 form: the weights are the MFMA's B operand (N = output channel); per wave
+// tile of 32 channels 4 fragments (N-tile nt = 0, 1 x hi | lo), float offset ((frag * 4 + tile) * 64 + lane) * 4; lane
+// (j = lane & 15, q = lane >> 4) holds W[row0 + 32 tile + 16 nt + j][32 hh + 8 q + 0..7][tap].
+static void pack_chunk16_sgb(float* dst, int row0, const float* w, int ci, int K, int tap, int hh) {
+    for (int frag = 0; frag < FRAGS_PER_CHUNK; ++frag)
+        for (int tile = 0; tile < 4; ++tile)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int nt = frag >> 1, part = frag & 1, j = lane & 15, q = lane >> 4;
+                const int o = row0 + 32 * tile + 16 * nt + j;
+                _Float16* oh = reinterpret_cast<_Float16*>(dst + ((size_t)(frag * 4 + tile) * 64 + lane) * 4);
+                for (int e = 0; e < 8; ++e) {
+                    const float v = w[((size_t)o * ci + 32 * hh + 8 * q + e) * K + tap];
+                    const _Float16 hi = (_Float16)v;
+                    oh[e] = part == 0 ? hi : (_Float16)(v - (float)hi);
+                }
+            }
+}
+
 extern "C" size_t stof_packed_weights_bytes(const stof_net_desc* desc) {
     if (check_desc(desc) != STOF_OK) return 0;
     PackedHeader h;
@@ -153,7 +171,8 @@ extern "C" int stof_pack_weights(const stof_net_desc* desc, const float* const* 
         for (int ocb = 0; ocb < 4; ++ocb)
             for (int t = 0; t < 5; ++t)
                 for (int hh = 0; hh < 2; ++hh) {
-                    pack_chunk(cc, 4, 128 * ocb, wc, NF_SGB, NF, 5, t, hh, desc->precision);
+                    if (desc->precision == STOF_PREC_F16X3 && body16_enabled()) pack_chunk16_sgb(cc, 128 * ocb, wc, NF, 5, t, hh);
+                    else pack_chunk(cc, 4, 128 * ocb, wc, NF_SGB, NF, 5, t, hh, desc->precision);
                     cc += SGB_CHUNK_F;
                 }
         const float* we = params[28];                                   // (64, 512, 5)

@@ -33,6 +33,8 @@ constexpr int ROWF = 68;
 //           fragment 2*m + part : lane (i = l&15, q = l>>4) -> part(W[body16_out_channel(block, m, i)][32*half + 8q + 0..7])
 //           The output-channel order inside a 32-channel block is permuted so that the accumulator lane (column = time row,
 //           q) of M-tiles m = 0, 1 holds the 8 CONSECUTIVE channels 8q .. 8q+7: one 16-byte LDS store per lane and row.
+//   f16x3 SemiGlobalBlock chunks, 16x16x32 (with the body): the weights are the B operand (N = output channel), time is on M:
+//           fragment 2*nt + part of wave tile `tile` : lane (j = l&15, q = l>>4) -> part(W[32 tile + 16 nt + j][32*half + 8q + 0..7])
 constexpr int FRAGS_PER_CHUNK = 4;
 constexpr int FRAG_F = 256;                                   // floats per fragment (1 KiB)
 constexpr int BODY_CHUNK_F = FRAGS_PER_CHUNK * 2 * FRAG_F;    // 2 output tiles (64 channels)

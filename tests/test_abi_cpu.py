@@ -86,6 +86,19 @@ def unpack_chunk16(chunk):
     return out
 
 
+def unpack_chunk16_sgb(chunk):
+    """SemiGlobalBlock contract chunk, 16x16x32 form: [4 frags = (N-tile nt, hi | lo)][4 wave tiles][64 lanes = (j, q)][8 fp16]
+    -> dense [128 out-channels][32 channels]; lane (j, q) of N-tile nt of tile t is channel 32 t + 16 nt + j, inputs 8 q .. + 7."""
+    halves = chunk.view(np.float16).reshape(4, 4, 64, 8).astype(np.float64)
+    out = np.zeros((128, 32), np.float64)
+    for nt in range(2):
+        for tile in range(4):
+            for lane in range(64):
+                j, q = lane & 15, lane >> 4
+                out[32 * tile + 16 * nt + j, 8 * q:8 * q + 8] = halves[2 * nt, tile, lane] + halves[2 * nt + 1, tile, lane]
+    return out
+
+
 @pytest.mark.parametrize('r,sgs,prec', [(4, 80, 0), (10, 80, 0), (4, 1, 0), (10, 80, 1), (20, 1, 1)])
 def test_pack_layout(lib, r, sgs, prec):
     sd = synth.synth_state_dict(r, seed=1, semi_global_scale=sgs)
@@ -137,7 +150,7 @@ def test_pack_layout(lib, r, sgs, prec):
         for ocb in range(4):
             for t in range(5):
                 for hh in range(2):
-                    dense = unpack_chunk(cc[ocb, t, hh], 4, prec)
+                    dense = unpack_chunk16_sgb(cc[ocb, t, hh]) if body16 else unpack_chunk(cc[ocb, t, hh], 4, prec)
                     ref = wc[128 * ocb:128 * ocb + 128, 32 * hh:32 * hh + 32, t]
                     assert close(dense, ref)
         we = sd['semi_global_block.expand_conv.weight']                      # (64, 512, 5)
