@@ -55,7 +55,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'], help="'train' = --config C5")
     ap.add_argument('--train-batch', type=int, default=256, help='waveforms per GPU per training step')
-    ap.add_argument('--train-precision', default='fp32', choices=['fp32', 'f16x3'],
+    ap.add_argument('--train-precision', default='f16x3', choices=['fp32', 'f16x3'],
                     help='arithmetic of the convolutions of the training step')
     ap.add_argument('--trainer', default='fused', choices=['fused', 'autograd'],
                     help="C5: 'fused' = StofNetTrainer (loss + AdamW kernels); 'autograd' = the reference's torch loss / "

@@ -297,6 +297,22 @@ int stof_train_upsample_add(const float* a, const float* e, float* out, int64_t 
                             int32_t rem_half, int32_t scale, void* stream);
 int stof_train_upsample_bwd(const float* g, const float* e, float* ge, int64_t N, int64_t L, int64_t P,
                             int32_t rem_half, int32_t scale, void* stream);
+/* Training forward on the fused sweep (split-fp16 mode; main.py:221 with the model in train mode): conv2 .. conv12 +
+ * conv_last of models/stofnet.py:51-65 in ONE launch of the inference body sweep, which additionally writes every layer's
+ * output to HBM for the backward pass -- instead of twelve stof_train_conv launches.
+ *   stof_train_sweep_pack : device-side packing of the CURRENT parameters (26 device pointers in stof_pack_weights order:
+ *                           conv1.weight, conv1.bias, conv2.weight, ..., conv12.bias, conv_last.weight, conv_last.bias) into
+ *                           the sweep's operand blob (stof_train_sweep_blob_bytes); no host copy of the weights
+ *   stof_train_sweep      : x[N][L] fp32; sgb_expand[N][floor(L/80)][64] = lrelu(expand_conv(pooled)) (stof_train_conv's
+ *                           output on the pooled grid; NULL for semi_global_scale 1); dump = stof_train_sweep_dump_floats
+ *                           floats: 12 channel-last tensors [N][L][64] (0: relu(conv1)+SemiGlobalBlock, 1..10: outputs of
+ *                           conv2..conv11 after their leaky ReLU / residual add, 11: conv12's) + a scratch tail;
+ *                           y[N][L*r] = the sample-shuffled prediction.  semi_global_scale 1 or 80 only.                  */
+size_t stof_train_sweep_blob_bytes(const stof_net_desc* desc);
+int stof_train_sweep_pack(const stof_net_desc* desc, const float* const* params_dev, void* blob_dev, void* stream);
+size_t stof_train_sweep_dump_floats(int64_t N, int64_t L);
+int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev, const float* x, const float* sgb_expand, float* dump,
+                     float* y, int64_t N, int64_t L, void* stream);
 /* Loss of main.py:228-232: target = amplitude * blur7(coords2mask(gt)) / max, loss = MSE + lambda * mean|pred|;
  * writes target[N*M], tmax[1], dpred[N*M] = grad_scale * dloss/dpred and loss[1] (double).  grad_scale is a power
  * of two (loss scaling: keeps the back-propagated values inside the fp16 range of the f16x3 mode); the weight-

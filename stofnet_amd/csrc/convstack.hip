@@ -198,6 +198,11 @@ struct BodyParams {
     // (virtual) waveform it touches; onsets_finalize_kernel turns them into counts / indices.  y may then be nullptr.
     OnsetPartial* onset_ws;       // [N][onset_slots] (this sub-batch), zeroed by the host side before the launch
     int onset_slots, onset_seg_slots;
+    // training forward (stof_train_sweep, 16x16x32 body only): every layer's output is also written to HBM, channel-last fp32
+    // [12][N][L][64]: tensor 0 = x0 (relu(conv1) + SemiGlobalBlock), 1..10 = outputs of conv2..conv11 (after leaky ReLU /
+    // residual add), 11 = conv12's; followed by >= 2 KiB the kernel may scribble on (rows that are padding)
+    float* dump;
+    long long dump_stride;        // floats per tensor = N * L * 64
 };
 
 // RF = floats per activation row: ROWF (272 B) for the 32-wide MFMA shapes; 72 (288 B) for the 16x16x32 body, whose
@@ -217,8 +222,9 @@ struct BodyLds {
 
 constexpr int ROWF16 = 72;        // 288-byte rows of the 16x16x32 body (see BodyLds)
 
-template <int PREC, int S, int RING, int RAWRING, int SHAPE = 32>
+template <int PREC, int S, int RING, int RAWRING, int SHAPE = 32, bool DUMP = false>
 __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) {
+    static_assert(!DUMP || SHAPE == 16, "the training dump lives in the 16x16x32 body");
     static_assert((RING & (RING - 1)) == 0 && (RAWRING & (RAWRING - 1)) == 0, "rings are powers of two");
     static_assert(S % 64 == 0 && S + 36 <= RING && S + 42 <= RAWRING, "ring must hold the live span");
     static_assert(SHAPE == 32 || (SHAPE == 16 && PREC == STOF_PREC_F16X3), "the 16x16x32 body is a split-fp16 kernel");
@@ -285,8 +291,9 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
     // load is issued before the first FMA so L2 latency is paid once per pass.
     // (nR, tR) = waveform / time of stream row `rstart`, maintained incrementally by the caller
     const float one_x0 = opaque_one();
-    auto x0_pass = [&](char* dst, int rstart, int nR, int tR) {
+    auto x0_pass = [&](char* dst, int rstart, int nR, int tR, bool dump_it) {
         constexpr int NIT = S / 16;
+        float* const dump0 = (DUMP && dump_it) ? p.dump : nullptr;
         const int g0 = rstart + rl * NIT;
         // Fast path (work-group uniform test): the pass's S rows lie inside ONE waveform, all of them real samples and (with a
         // SemiGlobalBlock) inside the up-sampled map -- the common case by far (a waveform is ~10 steps long).  Then no row
@@ -320,6 +327,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                     v[i] = fmaxf(a, 0.f) + sg[i];
                 }
                 char* const row = dst + ((g0 + it) & (RING - 1)) * ROWB;
+                if (dump0 != nullptr)
+                    st4(dump0 + ((size_t)(n0 + nR) * Ltrue + tR + rl * NIT + it) * NF + 4 * cq, make_float4(v[0], v[1], v[2], v[3]));
                 if constexpr (PREC == STOF_PREC_FP32) {
                     *reinterpret_cast<float4*>(row + 16 * cq) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
@@ -366,6 +375,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             }
             const float4 o = ok ? make_float4(v[0] + sg.x, v[1] + sg.y, v[2] + sg.z, v[3] + sg.w)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dump0 != nullptr && ok && t >= p.halo && t < p.halo + p.seg_len)        // a segment's own rows only
+                st4(dump0 + ((size_t)nw * Ltrue + tw) * NF + 4 * cq, o);
             store_act4<PREC>(dst + ((g0 + it) & (RING - 1)) * ROWB, 4 * cq, o);
         }
     };
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
         }
         __syncthreads();
         STAMP_ADD(0);                             // raw load + barrier
-        x0_pass(Xr, F - S, nS, tS);               // sweep layer 0
+        x0_pass(Xr, F - S, nS, tS, true);         // sweep layer 0
         STAMP_ADD(1);                             // x0 passes
         __syncthreads();
         STAMP_ADD(2);                             // barrier waits
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
             int nR = nS, tR = tS - layer_lag(j);
             while (tR < 0) { tR += Lp; nR -= 1; }
             if (j == 11) {                        // long skip: seed the destination with x0
-                x0_pass(Yr, F - S - 33, nR, tR);
+                x0_pass(Yr, F - S - 33, nR, tR, false);
                 STAMP_ADD(1);
                 __syncthreads();
                 STAMP_ADD(2);
@@ -670,6 +681,27 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                         acc[m][n] = mfma16(w[2 * m + (kk >= 4 ? 1 : 0)], b[(kk >> 1) == 1 ? 1 : 0], acc[m][n]);
                     };
                     const float one = opaque_one();
+                    // Wave-uniform test on the wave's S/2-row span: inside one waveform (and, in segment mode, inside the segment's
+                    // own rows), nothing but real samples?  Then no row needs masking and the training dump addresses are affine.
+                    const int offw0 = 16 * NN * ni, gw0 = R0 + offw0;
+                    int nkw, tkw, nww, tww;
+                    decode_row(nR, tR, offw0, nkw, tkw);
+                    vmap(n0 + nkw, tkw, nww, tww);
+                    const bool span_ok = (gw0 >= 0) && (gw0 + 16 * NN - 1 < gend) && (tkw + 16 * NN - 1 < L) && (tww >= 0) &&
+                                         (tww + 16 * NN - 1 < Ltrue) && (tkw >= p.halo) && (tkw + 16 * NN - 1 < p.halo + p.seg_len);
+                    // training dump of this layer's output (tensor j): lane = 8 consecutive channels of its row of every N-tile;
+                    // a span with padding rows writes to the scratch tail instead and is dumped row by row afterwards
+                    float* const dumpj = DUMP ? p.dump + (size_t)j * p.dump_stride : nullptr;
+                    float* dlane = nullptr;
+                    long long dstep = 0;
+                    if constexpr (DUMP) {
+                        if (span_ok) {
+                            dlane = dumpj + ((size_t)nww * Ltrue + tww + i16) * NF + 32 * mi + 8 * q4;
+                            dstep = 16 * NF;
+                        } else {
+                            dlane = p.dump + 12 * p.dump_stride + 8 * lane;
+                        }
+                    }
                     // The tail exists twice (in-place layers: old value + add; activation layers: leaky ReLU) so that the slices
                     // carry only the VALU work their layer needs.
                     auto tail = [&](auto inplace_c) {
@@ -713,6 +745,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                                     e.v[x0 + 1] = __builtin_amdgcn_fmed3f(e.v[x0 + 1], 0.01f * e.v[x0 + 1], 3.0e38f);
                                 }
                             } else if (st == 3) {
+                                if constexpr (DUMP) st4(dlane + n * dstep + 4 * m, make_float4(e.v[0], e.v[1], e.v[2], e.v[3]));
                                 e.h01 = cvt_h2(e.v[0], e.v[1]);
                                 e.h23 = cvt_h2(e.v[2], e.v[3]);
                                 e.v[0] = mix_sub(e.h01[0], e.v[0], one);
@@ -775,26 +808,26 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                     if (inplace) tail(std::true_type{});
                     else tail(std::false_type{});
                     // Rows outside [0, L) of their waveform (gap rows, stream ends, segment padding) must read as zeros for the
-                    // next layer (= its zero padding).  Wave-uniform test on the wave's S/2-row span: when the whole span lies
-                    // inside one waveform nothing is to do (the common case); otherwise the lanes of padding rows overwrite
-                    // what the branch-free tail stored (same lane, program order: no race; the barrier follows).
-                    {
-                        const int offw = 16 * NN * ni, g0 = R0 + offw;
-                        int nk0, tk0, nw0, tw0;
-                        decode_row(nR, tR, offw, nk0, tk0);
-                        vmap(n0 + nk0, tk0, nw0, tw0);
-                        const bool span_ok = (g0 >= 0) && (g0 + 16 * NN - 1 < gend) && (tk0 + 16 * NN - 1 < L) && (tw0 >= 0) &&
-                                             (tw0 + 16 * NN - 1 < Ltrue);
-                        if (!span_ok) {
+                    // next layer (= its zero padding).  When the wave's span lies inside one waveform nothing is to do (the
+                    // common case); otherwise the lanes of padding rows overwrite what the branch-free tail stored (same lane,
+                    // program order: no race; the barrier follows), and the training dump takes the valid rows of the span
+                    // from the LDS image (hi + lo = the value the next layer reads).
+                    if (!span_ok) {
 #pragma unroll 1
-                            for (int n = 0; n < NN; ++n) {
-                                bool valid;
-                                int slot, nw, tw, tk;
-                                row_of(n, valid, slot, nw, tw, tk);
-                                if (!valid) {
-                                    *reinterpret_cast<uint4*>(dst + slot) = make_uint4(0u, 0u, 0u, 0u);
-                                    *reinterpret_cast<uint4*>(dst + slot + 128) = make_uint4(0u, 0u, 0u, 0u);
-                                }
+                        for (int n = 0; n < NN; ++n) {
+                            bool valid;
+                            int slot, nw, tw, tk;
+                            row_of(n, valid, slot, nw, tw, tk);
+                            if (!valid) {
+                                *reinterpret_cast<uint4*>(dst + slot) = make_uint4(0u, 0u, 0u, 0u);
+                                *reinterpret_cast<uint4*>(dst + slot + 128) = make_uint4(0u, 0u, 0u, 0u);
+                            } else if (DUMP && tk >= p.halo && tk < p.halo + p.seg_len) {
+                                const half8 hh8 = as_h8(ldq(dst + slot)), ll8 = as_h8(ldq(dst + slot + 128));
+                                float* const o = dumpj + ((size_t)nw * Ltrue + tw) * NF + 32 * mi + 8 * q4;
+                                st4(o, make_float4((float)hh8[0] + (float)ll8[0], (float)hh8[1] + (float)ll8[1],
+                                                   (float)hh8[2] + (float)ll8[2], (float)hh8[3] + (float)ll8[3]));
+                                st4(o + 4, make_float4((float)hh8[4] + (float)ll8[4], (float)hh8[5] + (float)ll8[5],
+                                                       (float)hh8[6] + (float)ll8[6], (float)hh8[7] + (float)ll8[7]));
                             }
                         }
                     }
@@ -1595,6 +1628,7 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         bp.c1 = c1; bp.bias = bias; bp.chunks = body; bp.last16 = last16_use;
         bp.N = (int)nb; bp.L = (int)L; bp.r = r; bp.P = (int)P; bp.rem_half = (int)(rem / 2);
         bp.stamps = nullptr;
+        bp.dump = nullptr; bp.dump_stride = 0;
         bp.status = status;
         bp.run_if = run_if;
         // Cut every waveform into 2^k segments (each swept with +-38 rows of real context, the receptive field of
@@ -1753,6 +1787,153 @@ extern "C" int stof_forward_auto(const stof_net_desc* desc, const void* packed_f
     // exact-fp32 re-run of the whole call, gated on the device by the range-guard word: its three launches return at
     // once while *status_dev == 0, so the common case costs three empty launches and no host synchronisation
     return forward_impl(&d32, packed_fp32_dev, x, y, N, L, workspace, workspace_bytes, stream, nullptr, nullptr, status_dev);
+}
+
+// ----------------------------------------------------------------------------------
+// Training forward on the sweep (main.py:221 in train mode): conv2 .. conv12 + conv_last of the split-fp16
+// training step run as ONE body sweep that also writes every layer's output to HBM for the backward pass, instead of twelve
+// layer-by-layer launches.  The parameters change every step, so the sweep's operand blob is packed ON THE DEVICE.
+// ----------------------------------------------------------------------------------
+namespace {
+
+struct SweepPackArgs {
+    const float* p[26];       // conv1.w, conv1.b, conv2.w, conv2.b, ..., conv12.b, conv_last.w, conv_last.b (stof_pack_weights order)
+    float* blob;              // header-less: [c1 640][bias 832][body BODY_NCHUNK * BODY_CHUNK_F][last16 LAST16_F if r <= 16]
+    int r;
+};
+
+__global__ __launch_bounds__(256) void sweep_pack_kernel(const SweepPackArgs a) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    const long long n_c1 = 640, n_bias = 13 * 64, n_body = (long long)BODY_NCHUNK * BODY_CHUNK_F * 2;   // body counted in fp16 halves
+    const long long n_last = a.r <= 16 ? (long long)LAST16_F * 2 : 0;
+    if (i < n_c1) {
+        const int c = (int)(i / 10), t = (int)(i % 10);
+        a.blob[i] = t < 9 ? a.p[0][c * 9 + t] : a.p[1][c];
+        return;
+    }
+    long long k = i - n_c1;
+    if (k < n_bias) {
+        const int j = (int)(k / 64), c = (int)(k % 64);
+        float v = 0.f;
+        if (j >= 1 && j <= 11) v = a.p[3 + 2 * (j - 1)][c];
+        else if (j == 12 && c < a.r) v = a.p[25][c];
+        a.blob[n_c1 + k] = v;
+        return;
+    }
+    k -= n_bias;
+    _Float16* const body = reinterpret_cast<_Float16*>(a.blob + n_c1 + n_bias);
+    if (k < n_body) {
+        // half index -> (chunk, frag, block, lane, e), the order of pack_chunk16 (pack_weights.cpp)
+        const int e = (int)(k & 7), lane = (int)((k >> 3) & 63), blk = (int)((k >> 9) & 1), frag = (int)((k >> 10) & 3);
+        const int c = (int)(k >> 12);
+        const int j = c < 11 * BODY_CHUNKS_K7 ? 1 + c / BODY_CHUNKS_K7 : 12;
+        const int cc = c < 11 * BODY_CHUNKS_K7 ? c % BODY_CHUNKS_K7 : c - 11 * BODY_CHUNKS_K7;
+        const int K = j == 12 ? 3 : 7, co = j == 12 ? a.r : NF;
+        const int tap = cc >> 1, hh = cc & 1, m = frag >> 1, part = frag & 1, i16 = lane & 15, q = lane >> 4;
+        const int o = body16_out_channel(blk, m, i16), ch = 32 * hh + 8 * q + e;
+        const float* w = j == 12 ? a.p[24] : a.p[2 + 2 * (j - 1)];
+        const float v = o < co ? w[((size_t)o * NF + ch) * K + tap] : 0.f;
+        const _Float16 hi = (_Float16)v;
+        body[k] = part == 0 ? hi : (_Float16)(v - (float)hi);
+        return;
+    }
+    k -= n_body;
+    if (k < n_last) {
+        // [6 chunks][hi | lo][64 lanes][8]: conv_last as 16x16x32 A operands, rows >= r zero
+        const int e = (int)(k & 7), lane = (int)((k >> 3) & 63), part = (int)((k >> 9) & 1), cc = (int)(k >> 10);
+        const int tap = cc >> 1, hh = cc & 1, o = lane & 15, ch = 32 * hh + 8 * (lane >> 4) + e;
+        const float v = o < a.r ? a.p[24][((size_t)o * NF + ch) * 3 + tap] : 0.f;
+        const _Float16 hi = (_Float16)v;
+        reinterpret_cast<_Float16*>(a.blob + n_c1 + n_bias + (long long)BODY_NCHUNK * BODY_CHUNK_F)[k] = part == 0 ? hi : (_Float16)(v - (float)hi);
+    }
+}
+
+inline size_t sweep_blob_floats(int r) {
+    return 640 + 13 * 64 + (size_t)BODY_NCHUNK * BODY_CHUNK_F + (r <= 16 ? LAST16_F : 0);
+}
+
+}  // namespace
+
+extern "C" size_t stof_train_sweep_blob_bytes(const stof_net_desc* desc) {
+    if (!desc || desc->upsample_factor < 1 || desc->upsample_factor > 64) return 0;
+    return sweep_blob_floats(desc->upsample_factor) * sizeof(float);
+}
+
+extern "C" int stof_train_sweep_pack(const stof_net_desc* desc, const float* const* params_dev, void* blob_dev, void* stream) {
+    if (!desc || !params_dev || !blob_dev) return STOF_ERR_BAD_ARG;
+    if (desc->upsample_factor < 1 || desc->upsample_factor > 64) return STOF_ERR_UNSUPPORTED;
+    SweepPackArgs a;
+    for (int i = 0; i < 26; ++i) {
+        if (!params_dev[i]) return STOF_ERR_BAD_ARG;
+        a.p[i] = params_dev[i];
+    }
+    a.blob = static_cast<float*>(blob_dev);
+    a.r = desc->upsample_factor;
+    const long long total = 640 + 13 * 64 + (long long)BODY_NCHUNK * BODY_CHUNK_F * 2 + (a.r <= 16 ? (long long)LAST16_F * 2 : 0);
+    hipLaunchKernelGGL(sweep_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" size_t stof_train_sweep_dump_floats(int64_t N, int64_t L) {
+    if (N <= 0 || L <= 0) return 0;
+    return (size_t)12 * N * L * NF + 1024;
+}
+
+extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev, const float* x, const float* sgb_expand,
+                                float* dump, float* y, int64_t N, int64_t L, void* stream_) {
+    if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
+    const int r = desc->upsample_factor;
+    if (r < 1 || r > 64) return STOF_ERR_UNSUPPORTED;
+    const bool has_sgb = desc->semi_global_scale != 1;
+    if (has_sgb && desc->semi_global_scale != SGB_SCALE) return STOF_ERR_UNSUPPORTED;
+    const int64_t P = has_sgb ? L / SGB_SCALE : 0;
+    if (has_sgb && L > 0 && P == 0) return STOF_ERR_POOL_EMPTY;
+    if (has_sgb && ((L - P * SGB_SCALE) & 1)) return STOF_ERR_ODD_SGB_REMAINDER;
+    if (N == 0 || L == 0) return STOF_OK;
+    if (!blob_dev || !x || !dump || !y || (has_sgb && !sgb_expand)) return STOF_ERR_BAD_ARG;
+    if ((L + GAP) * N > 0x7fffffffLL || N * L * NF > 0x7fffffffffLL) return STOF_ERR_UNSUPPORTED;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    using Lds16 = BodyLds<BODY_S, BODY_RING, BODY_RAWRING, ROWF16>;
+    auto kernel = &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true>;
+    static LdsLimitOnce lds;
+    if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)Lds16::BYTES)) return st;
+    const float* base = static_cast<const float*>(blob_dev);
+    BodyParams bp;
+    bp.x = x; bp.sgb = has_sgb ? sgb_expand : nullptr; bp.y = y;
+    bp.c1 = base; bp.bias = base + 640; bp.chunks = base + 640 + 13 * 64;
+    bp.last16 = r <= 16 ? bp.chunks + (size_t)BODY_NCHUNK * BODY_CHUNK_F : nullptr;
+    bp.L = (int)L; bp.r = r; bp.P = (int)P; bp.rem_half = (int)((L - P * SGB_SCALE) / 2);
+    bp.stamps = nullptr; bp.status = nullptr; bp.run_if = nullptr;
+    bp.onset_ws = nullptr; bp.onset_slots = 0; bp.onset_seg_slots = 0;
+    bp.dump = dump; bp.dump_stride = (long long)N * L * NF;
+    // segments as in the inference launch: few waveforms per CU leave work-groups idle otherwise
+    const int ncu = device_cu_count();
+    bp.nseg_log2 = 0;
+    {
+        int64_t best = -1;
+        for (int k = 0; k <= 5; ++k) {
+            const int64_t ns = (int64_t)1 << k;
+            if (k > 0 && L / ns < BODY_S / 2) break;
+            const int64_t lv = (L + ns - 1) / ns + (k > 0 ? 76 : 0);
+            const int64_t nvk = N * ns;
+            const int64_t w = nvk < ncu ? nvk : ncu;
+            const int64_t per = (nvk + w - 1) / w;
+            const int64_t steps = (per * (lv + GAP) - GAP + LAG_LAST + BODY_S - 1) / BODY_S;
+            if (best < 0 || steps < best) { best = steps; bp.nseg_log2 = k; }
+        }
+    }
+    if (desc->seg_policy > 0) bp.nseg_log2 = desc->seg_policy - 1;
+    const int64_t nseg = (int64_t)1 << bp.nseg_log2;
+    bp.seg_len = (int)((L + nseg - 1) / nseg);
+    bp.halo = nseg > 1 ? 38 : 0;
+    const int64_t nv = N * nseg;
+    if ((int64_t)(bp.seg_len + 2 * bp.halo + GAP) * nv > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    bp.N = (int)nv;
+    int64_t wgs = nv < ncu ? nv : ncu;
+    bp.wf_per_wg = (int)((nv + wgs - 1) / wgs);
+    wgs = (nv + bp.wf_per_wg - 1) / bp.wf_per_wg;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), Lds16::BYTES, stream, bp);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
 extern "C" int stof_events_create(int32_t count, void** events_out) {

@@ -68,7 +68,7 @@ constexpr uint32_t PACK_MAGIC = 0x464F5453u;
 
 // 16x16x32 body: output channel held by row i (0..15) of M-tile m (0, 1) of the 32-channel block `block`:
 // accumulator element e of lane (col, q) is row 4q + e, i.e. channel 32 block + 8q + 4m + e.
-inline int body16_out_channel(int block, int m, int i) { return 32 * block + 8 * (i >> 2) + 4 * m + (i & 3); }
+constexpr int body16_out_channel(int block, int m, int i) { return 32 * block + 8 * (i >> 2) + 4 * m + (i & 3); }
 inline bool body16_enabled() {
     const char* e = getenv("STOF_BODY16");
     return e == nullptr || e[0] != '0';

@@ -83,7 +83,7 @@ class SemiGlobalBlock(nn.Module):
 class StofNet(nn.Module):
 
     def __init__(self, upsample_factor=4, num_features=64, num_blocks=13, kernel_sizes=[9, 7, 3], in_channels=1,
-                 semi_global_scale=80, weights_init=False, precision='auto', train_precision='fp32'):
+                 semi_global_scale=80, weights_init=False, precision='auto', train_precision='f16x3'):
         super().__init__()
         self.num_blocks = num_blocks
         self.in_channels = in_channels

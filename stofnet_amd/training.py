@@ -41,6 +41,12 @@ class TrainEngine:
         # SemiGlobalBlock geometry (models/stofnet.py:83-85): pool / upsample by `scale`, feat_scale = max(1, scale // 10)
         self.scale = int(scale)
         self.cmid = 64 * max(1, self.scale // 10)
+        # split-fp16 mode: conv2..conv12 + conv_last of the forward run as ONE fused sweep that also writes every layer's
+        # output for the backward pass (stof_train_sweep) instead of twelve layer launches; STOF_TRAIN_SWEEP=0 keeps the layers
+        import os
+        self.sweep = (self.prec == 1 and (not self.sgb or self.scale == 80) and os.environ.get('STOF_TRAIN_SWEEP', '1') != '0'
+                      and os.environ.get('STOF_BODY16', '1') != '0')
+        self._sweep_blob = None
         if self.sgb and not 2 <= self.scale <= 256:
             raise NotImplementedError('SemiGlobalBlock sample_scale must be in [2, 256] for the gfx950 kernels')
         self._gscale = 1.0
@@ -100,12 +106,44 @@ class TrainEngine:
             raise RuntimeError(f'The size of tensor a ({L}) must match the size of tensor b ({L - 1}) at non-singleton dimension 2')
         sg = 'semi_global_block.'
         st = self._st()
-        fwd = {k[:-7]: self._repack(v, False) for k, v in p.items() if k.endswith('.weight') and k != 'conv1.weight'}
+        use_sweep = self.sweep and 'conv2.weight' in p
+        head = ('semi_global_block.',) if use_sweep else ('conv', 'semi_global_block.')        # layers that still run one by one
+        fwd = {k[:-7]: self._repack(v, False) for k, v in p.items()
+               if k.endswith('.weight') and k != 'conv1.weight' and k.startswith(head)}
         bwd = {k[:-7]: self._repack(v, True) for k, v in p.items() if k.endswith('.weight') and k != 'conv1.weight'} if keep else None
         a1 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
         _lib.check(lib.stof_train_conv1(_lib.ptr(x), _lib.ptr(p['conv1.weight']), _lib.ptr(p['conv1.bias']), _lib.ptr(a1),
                                         n, L, st), 'stof_train_conv1')
         c = pooled = arg = e = None
+        if use_sweep:
+            # SemiGlobalBlock up to the expand conv on the layer kernels (the backward pass needs c / pooled / arg); its
+            # up-sampled map is added inside the sweep, which recomputes relu(conv1) from x
+            if self.sgb:
+                c, pooled, arg, e = self._sgb_head(a1, fwd[sg + 'contract_conv'], p[sg + 'contract_conv.bias'],
+                                                   fwd[sg + 'expand_conv'], p[sg + 'expand_conv.bias'])
+            desc = _lib.NetDesc(int(r), 80 if self.sgb else 1, _lib.PREC_F16X3, 0)
+            import ctypes
+            nbytes = lib.stof_train_sweep_blob_bytes(ctypes.byref(desc))
+            if self._sweep_blob is None or self._sweep_blob.numel() < nbytes:
+                self._sweep_blob = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            names = ['conv1'] + [f'conv{i}' for i in range(2, 13)] + ['conv_last']
+            arr = (ctypes.c_void_p * 26)()
+            for i, nm in enumerate(names):
+                arr[2 * i] = _lib.ptr(p[nm + '.weight'].contiguous())
+                arr[2 * i + 1] = _lib.ptr(p[nm + '.bias'].contiguous())
+            _lib.check(lib.stof_train_sweep_pack(ctypes.byref(desc), arr, _lib.ptr(self._sweep_blob), st), 'stof_train_sweep_pack')
+            dump = torch.empty(lib.stof_train_sweep_dump_floats(n, L), dtype=torch.float32, device=self.dev)
+            z = torch.empty((n, L * r), dtype=torch.float32, device=self.dev)
+            _lib.check(lib.stof_train_sweep(ctypes.byref(desc), _lib.ptr(self._sweep_blob), _lib.ptr(x), _lib.ptr(e), _lib.ptr(dump),
+                                            _lib.ptr(z), n, L, st), 'stof_train_sweep')
+            if not keep:
+                return z, None
+            t = dump[:12 * n * L * 64].view(12, n, L, 64)
+            xs = [t[0]] + [t[2 + 2 * k] for k in range(5)]
+            ys = [t[1 + 2 * k] for k in range(5)]
+            saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=t[11], bwd=bwd, n=n, L=L, P=P, rem=rem,
+                         _dump=dump)
+            return z, saved
         if self.sgb:
             x0, c, pooled, arg, e = self._sgb_forward(a1, fwd[sg + 'contract_conv'], p[sg + 'contract_conv.bias'],
                                                       fwd[sg + 'expand_conv'], p[sg + 'expand_conv.bias'])
@@ -129,19 +167,28 @@ class TrainEngine:
         saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=x6, bwd=bwd, n=n, L=L, P=P, rem=rem)
         return z.view(n, L * r), saved
 
-    def _sgb_forward(self, a1, w_contract, b_contract, w_expand, b_expand):
-        """SemiGlobalBlock.forward (models/stofnet.py:98-117) on channel-last a1 [N, L, 64]:
-        a1 + pad(upsample(lrelu(expand(maxpool(lrelu(contract(a1))))))).  Returns (out, c, pooled, arg, e)."""
+    def _sgb_head(self, a1, w_contract, b_contract, w_expand, b_expand):
+        """contract conv -> lrelu -> max-pool -> expand conv -> lrelu (models/stofnet.py:100-107) on channel-last a1."""
         lib, st = _lib.lib(), self._st()
         n, L = a1.shape[0], a1.shape[1]
         S, cm = self.scale, self.cmid
         P = L // S
-        rem = L - S * P
         c = self._conv(a1, w_contract, b_contract, 64, cm, 5, ACT_LRELU)
         pooled = torch.empty((n, max(P, 1), cm), dtype=torch.float32, device=self.dev)[:, :P]
         arg = torch.empty((n, max(P, 1), cm), dtype=torch.uint8, device=self.dev)[:, :P]
         _lib.check(lib.stof_train_pool(_lib.ptr(c), _lib.ptr(pooled), _lib.ptr(arg), n, L, P, cm, S, st), 'stof_train_pool')
         e = self._conv(pooled, w_expand, b_expand, cm, 64, 5, ACT_LRELU)
+        return c, pooled, arg, e
+
+    def _sgb_forward(self, a1, w_contract, b_contract, w_expand, b_expand):
+        """SemiGlobalBlock.forward (models/stofnet.py:98-117) on channel-last a1 [N, L, 64]:
+        a1 + pad(upsample(lrelu(expand(maxpool(lrelu(contract(a1))))))).  Returns (out, c, pooled, arg, e)."""
+        lib, st = _lib.lib(), self._st()
+        n, L = a1.shape[0], a1.shape[1]
+        S = self.scale
+        P = L // S
+        rem = L - S * P
+        c, pooled, arg, e = self._sgb_head(a1, w_contract, b_contract, w_expand, b_expand)
         out = torch.empty_like(a1)
         _lib.check(lib.stof_train_upsample_add(_lib.ptr(a1), _lib.ptr(e), _lib.ptr(out), n, L, P, rem // 2, S, st),
                    'stof_train_upsample_add')
@@ -243,7 +290,7 @@ class StofNetTrainer(TrainEngine):
     buffer so the optimizer kernel and the gradient all-reduce touch a single tensor."""
 
     def __init__(self, model: StofNet, lr=5e-4, weight_decay=1e-8, lambda_value=1e-2, mask_amplitude=20,
-                 kernel_size=7, sigma=1, betas=(0.9, 0.999), eps=1e-8, process_group=None, precision='fp32'):
+                 kernel_size=7, sigma=1, betas=(0.9, 0.999), eps=1e-8, process_group=None, precision='f16x3'):
         if not model._supported():
             raise NotImplementedError('only the shipped StofNet architecture is supported')
         if kernel_size != 7:
