@@ -295,6 +295,206 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(const ConvParams p) {
     }   // persistent tile loop
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Split-fp16 channel-last convolution on v_mfma_f32_16x16x32_f16 for channel counts that are multiples of 64 (the twelve
+// 64 -> 64 data-gradient convolutions of a training step, the 64 <-> 512 SemiGlobalBlock ones).  Same contract as
+// conv_cl_kernel; what differs is the machinery, which is the inference sweep's:
+//   * weights in MFMA-fragment order (repack_frag16_kernel), fetched L2 -> registers two chunks ahead -- no LDS staging
+//     of weights and therefore no work-group barrier per (tap, channel block) step, only one per 64-channel input block
+//   * the 16x16x32 shape (about 12 % more flops per watt than 32x32x16 on this part, tools/micro/mfma_shape_lds.hip)
+//   * activation rows of 288 bytes: the operand reads (lane = (time row, k-group)) are bank-conflict free
+//   * the output-channel order inside a 32-channel block is permuted (body16_out_channel) so that a lane ends up with
+//     8 consecutive channels of its row: 32-byte loads / stores of bias, residual, saved activation and output
+// Work-group tile: CT16 = 128 rows x 64 output channels; wave (mi, ni): channels 32 mi .., rows 64 ni .. = 2 M-tiles x 4
+// N-tiles; chunk = (tap, 32-channel half) of one 64-channel input block: 4 weight fragments, 8 activation fragments, 24 MFMAs.
+// ----------------------------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int CT16 = 128;
+constexpr int ROWB16 = 288;
+
+__device__ __forceinline__ half8 as_h8(uint4 v) {
+    union { uint4 u; half8 h; } c;
+    c.u = v;
+    return c.h;
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void conv_cl16_kernel(const ConvParams p) {
+    constexpr int PAD = K / 2, ROWS = CT16 + K - 1, NCH = 2 * K;          // chunks per input block
+    __shared__ __attribute__((aligned(16))) char xs[(CT16 + 8) * ROWB16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = wave & 1, ni = wave >> 1, i16 = lane & 15, q4 = lane >> 4;
+    const int ob = blockIdx.y, o0 = ob * 64;
+    const int ncb = p.cin >> 6;
+    const int nchunk = ncb * NCH;                                          // chunks per tile
+    // fragment image: [ob][cb][tap][hh][frag 4][mi 2][lane 64][8 halves]; a wave's fragment f of chunk c:
+    const uint4* const wbase = reinterpret_cast<const uint4*>(p.w) + (size_t)ob * nchunk * 512 + mi * 64 + lane;
+    auto wload = [&](int c, int f) -> uint4 { return wbase[((size_t)c * 4 + f) * 128]; };
+    // activation tile of one 64-channel block, HBM -> registers one (tile, block) ahead
+    constexpr int NXR = ((CT16 + 8) * 16 + 255) / 256;
+    float4 xreg[NXR];
+    auto xfetch = [&](int tile, int cb) {
+        const int n = tile / p.tiles_per_wf;
+        const int t0 = (tile - n * p.tiles_per_wf) * CT16;
+#pragma unroll
+        for (int u = 0; u < NXR; ++u) {
+            const int i = tid + 256 * u, r = i >> 4, q = i & 15;
+            const int t = t0 - PAD + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < ROWS && t >= 0 && t < p.L) v = ld4(p.x + ((size_t)n * p.L + t) * p.cin + (cb << 6) + 4 * q);
+            xreg[u] = v;
+        }
+    };
+    uint4 wf[2][4];
+    if ((int)blockIdx.x < p.total_tiles) {
+        xfetch(blockIdx.x, 0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { wf[0][f] = wload(0, f); wf[1][f] = wload(1, f); }
+    }
+    auto mfma16 = [](const uint4& a, const uint4& b, floatx4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(a), as_h8(b), c, 0, 0, 0);
+    };
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+        const int n = tile / p.tiles_per_wf;
+        const int t0 = (tile - n * p.tiles_per_wf) * CT16;
+        const bool more = tile + (int)gridDim.x < p.total_tiles;
+        floatx4 acc[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[m][k][e] = 0.f;
+        int c = 0;                                                         // chunk index within the tile
+        for (int cb = 0; cb < ncb; ++cb) {
+            __syncthreads();                                               // the previous block's fragments have been read
+#pragma unroll
+            for (int u = 0; u < NXR; ++u) {
+                const int i = tid + 256 * u, r = i >> 4, q = i & 15;
+                if (r >= CT16 + 8) continue;
+                uint2 hi, lo;
+                split4(xreg[u], hi, lo);
+                char* row = xs + r * ROWB16;
+                *reinterpret_cast<uint2*>(row + 8 * q) = hi;
+                *reinterpret_cast<uint2*>(row + 128 + 8 * q) = lo;
+            }
+            if (cb + 1 < ncb) xfetch(tile, cb + 1);
+            else if (more) xfetch(tile + gridDim.x, 0);
+            __syncthreads();
+            const char* const bbase = xs + (64 * ni + i16) * ROWB16 + 16 * q4;
+            auto bload = [&](uint4 (&b)[4][2], int cc) {                   // cc = 2 tap + half
+                const char* row = bbase + (cc >> 1) * ROWB16 + 64 * (cc & 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { b[k][0] = *reinterpret_cast<const uint4*>(row + 16 * k * ROWB16);
+                                              b[k][1] = *reinterpret_cast<const uint4*>(row + 16 * k * ROWB16 + 128); }
+            };
+            auto do_chunk = [&](uint4 (&w)[4], uint4 (&bcur)[4][2], uint4 (&bnext)[4][2], int cc) {
+                int c2 = c + 2;
+                if (c2 >= nchunk) c2 -= nchunk;                            // wraps to the next tile's first chunks (same weights)
+                if (cc + 1 < NCH) bload(bnext, cc + 1);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                    for (int k = 0; k < 4; k += 2) {
+                        acc[m][k] = mfma16(w[2 * m], bcur[k][0], acc[m][k]);
+                        acc[m][k + 1] = mfma16(w[2 * m], bcur[k + 1][0], acc[m][k + 1]);
+                        acc[m][k] = mfma16(w[2 * m], bcur[k][1], acc[m][k]);
+                        acc[m][k + 1] = mfma16(w[2 * m], bcur[k + 1][1], acc[m][k + 1]);
+                        acc[m][k] = mfma16(w[2 * m + 1], bcur[k][0], acc[m][k]);
+                        acc[m][k + 1] = mfma16(w[2 * m + 1], bcur[k + 1][0], acc[m][k + 1]);
+                    }
+                    w[2 * m] = wload(c2, 2 * m);
+                    w[2 * m + 1] = wload(c2, 2 * m + 1);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                }
+                ++c;
+            };
+            uint4 bf0[4][2], bf1[4][2];
+            bload(bf0, 0);
+#pragma unroll
+            for (int cc = 0; cc < NCH; cc += 2) {
+                do_chunk(wf[0], bf0, bf1, cc);
+                do_chunk(wf[1], bf1, bf0, cc + 1);
+            }
+        }
+        // ---- epilogue: lane (i16, q4) holds channels o0 + 32 mi + 8 q4 + 4 m + e of rows t0 + 64 ni + 16 k + i16
+        const int och = o0 + 32 * mi + 8 * q4;
+        float bi[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            const float4 b0 = ld4(p.bias + och), b1 = ld4(p.bias + och + 4);
+            bi[0] = b0.x; bi[1] = b0.y; bi[2] = b0.z; bi[3] = b0.w; bi[4] = b1.x; bi[5] = b1.y; bi[6] = b1.z; bi[7] = b1.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = t0 + 64 * ni + 16 * k + i16;
+            if (t >= p.L) continue;
+            const size_t off = ((size_t)n * p.L + t) * p.cout + och;
+            float v[8], rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sv[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+            if (p.residual) {
+                const float4 a = ld4(p.residual + off), b = ld4(p.residual + off + 4);
+                rs[0] = a.x; rs[1] = a.y; rs[2] = a.z; rs[3] = a.w; rs[4] = b.x; rs[5] = b.y; rs[6] = b.z; rs[7] = b.w;
+            }
+            if (p.saved) {
+                const float4 a = ld4(p.saved + off), b = ld4(p.saved + off + 4);
+                sv[0] = a.x; sv[1] = a.y; sv[2] = a.z; sv[3] = a.w; sv[4] = b.x; sv[5] = b.y; sv[6] = b.z; sv[7] = b.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = acc[e >> 2][k][e & 3] + bi[e];
+                if (p.saved == nullptr) {                       // forward
+                    if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+                    else if (p.act == ACT_LRELU) x = x > 0.f ? x : 0.01f * x;
+                    x += rs[e];
+                } else {                                        // backward: (grad + residual grad) * act'(saved)
+                    x += rs[e];
+                    if (p.act == ACT_RELU) x = sv[e] > 0.f ? x : 0.f;
+                    else if (p.act == ACT_LRELU) x = sv[e] > 0.f ? x : 0.01f * x;
+                }
+                v[e] = x;
+            }
+            *reinterpret_cast<float4*>(p.y + off) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(p.y + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
+// operand image of conv_cl16_kernel: W'[d][a][b] (a = output, b = input index of the convolution that runs: forward
+// W'[d][o][c] = w[o][c][d]; data gradient W'[d][c][o] = w[o][c][K-1-d]) as fp16 hi | lo MFMA fragments
+// [a/64][b/64][d][half][frag = 2 m + part][block][lane = (i, q)][8]: a = 64 (a/64) + body16_out_channel(block, m, i),
+// b = 64 (b/64) + 32 half + 8 q + e.  One thread per fp16 element.
+__global__ void repack_frag16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int cout, int cin, int K,
+                                     int transpose_flip) {
+    const int A = transpose_flip ? cin : cout, B = transpose_flip ? cout : cin;
+    const long long total = (long long)K * A * B * 2;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), blk = (int)((i >> 9) & 1), frag = (int)((i >> 10) & 3);
+    long long c = i >> 12;                                     // chunk index: ((ab * ncb + cb) * K + d) * 2 + hh
+    const int hh = (int)(c & 1);
+    c >>= 1;
+    const int d = (int)(c % K);
+    c /= K;
+    const int ncb = B >> 6;
+    const int cb = (int)(c % ncb), ab = (int)(c / ncb);
+    const int m = frag >> 1, part = frag & 1, i16 = lane & 15, q = lane >> 4;
+    const int a = 64 * ab + body16_out_channel(blk, m, i16), b = 64 * cb + 32 * hh + 8 * q + e;
+    const float v = transpose_flip ? w[((size_t)b * cin + a) * K + (K - 1 - d)] : w[((size_t)a * cin + b) * K + d];
+    const _Float16 h = (_Float16)v;
+    out[i] = part == 0 ? h : (_Float16)(v - (float)h);
+}
+
+__host__ __device__ inline bool conv_cl16_ok(int cin, int cout, int K, int precision) {
+    return precision == STOF_PREC_F16X3 && (cin & 63) == 0 && (cout & 63) == 0 && (K == 3 || K == 5 || K == 7);
+}
+
 // w_out[d][a][b] = w_in[b][a][K-1-d]  (torch layout (cout, cin, K) -> tap-major [K][cin][cout] flipped: dgrad)
 // or w_out[d][o][c] = w_in[o][c][d]   (forward)
 __global__ void repack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int K,
@@ -838,6 +1038,22 @@ int launch_conv_cl(const float* x, const float* w, const float* bias, const floa
     const int64_t tiles = N * p.tiles_per_wf;
     if (tiles > 0x7fffffffLL || N * L > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
     p.total_tiles = (int)tiles;
+    static const bool fast16 = stof::body16_enabled();
+    if (period == 0 && run_if == nullptr && fast16 && conv_cl16_ok(cin, cout, K, precision)) {
+        p.tiles_per_wf = (int)((L + CT16 - 1) / CT16);
+        const int64_t tiles16 = N * p.tiles_per_wf;
+        if (tiles16 > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+        p.total_tiles = (int)tiles16;
+        const int ob = cout / 64;
+        int64_t g16 = 512 / ob;                      // persistent: 2 work-groups per CU
+        if (g16 < 1) g16 = 1;
+        if (g16 > tiles16) g16 = tiles16;
+        const dim3 grid16((unsigned)g16, (unsigned)ob);
+        if (K == 3) hipLaunchKernelGGL(conv_cl16_kernel<3>, grid16, dim3(256), 0, stream, p);
+        else if (K == 5) hipLaunchKernelGGL(conv_cl16_kernel<5>, grid16, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(conv_cl16_kernel<7>, grid16, dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+    }
     const int oblocks = (cout + 63) / 64;
     int64_t gx = 512 / oblocks;                      // persistent: 2 work-groups per CU (71 KB of LDS each)
     if (gx < 1) gx = 1;
@@ -878,6 +1094,14 @@ extern "C" size_t stof_train_repack_floats(int32_t cout, int32_t cin, int32_t K,
 extern "C" int stof_train_repack(const float* w, float* out, int32_t cout, int32_t cin, int32_t K, int32_t transpose_flip,
                                  int32_t precision, void* stream) {
     if (!w || !out || cout < 1 || cin < 1 || K < 1) return STOF_ERR_BAD_ARG;
+    static const bool fast16 = stof::body16_enabled();
+    if (fast16 && conv_cl16_ok(cin, cout, K, precision)) {
+        // fragment image of conv_cl16_kernel (the conv entry point picks that kernel by the same test); same size
+        const long long halves = (long long)K * cout * cin * 2;
+        hipLaunchKernelGGL(repack_frag16_kernel, dim3(blocks_for(halves)), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                           reinterpret_cast<_Float16*>(out), cout, cin, K, transpose_flip);
+        return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+    }
     if (precision == STOF_PREC_F16X3) {
         const long long total = (long long)stof_train_repack_floats(cout, cin, K, transpose_flip, precision);
         hipLaunchKernelGGL(repack_weights_split_kernel, dim3(blocks_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
