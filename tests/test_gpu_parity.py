@@ -996,3 +996,33 @@ def test_pala_gradpeak_configuration_end_to_end(dev, tmp_path, thn, th):
     es4, _ = entry.main(['model=gradpeak', f'input_file={path}', 'data_dir=/data/PALA_data_InSilicoFlow', 'rf_scale_factor=20',
                          f'th={th}', 'batch_size=2'])
     assert np.array_equal(pad(es4), pad(want))
+
+
+def test_body_mfma_shape_switch_gives_the_same_maps(dev):
+    """STOF_BODY16=0 (read by the packer and the launcher of ONE process) selects the 32x32x16 form of the split-fp16
+    body / SemiGlobalBlock kernels kept for A/B runs: same maps within rounding, same onset indices, same golden parity."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import golden, load_weights
+from stofnet_amd import StofNet
+g = golden('f1_armadillo_r4_L2000')
+m = StofNet(upsample_factor=4, precision='f16x3')
+m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in load_weights('different-armadillo').items()}, strict=True)
+y = m.to('cuda:0').eval()(torch.from_numpy(g['x']).cuda()).cpu().numpy()
+err = np.abs(y - g['y']).max() / np.abs(g['y']).max()
+assert err < 1e-5, err
+assert np.array_equal(y[:, 0].argmax(-1), g['y'][:, 0].argmax(-1))
+np.save(sys.argv[1], y)
+print('ok', err)
+''' % (os.path.dirname(os.path.dirname(GOLDEN)), os.path.dirname(GOLDEN))
+    outs = []
+    for flag in ('1', '0'):
+        path = f'/tmp/stof_body16_{flag}.npy'
+        env = dict(os.environ, STOF_BODY16=flag)
+        p = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(np.load(path))
+    assert rel_err(outs[0], outs[1]) < 4e-6          # two roundings of the same sum in different orders
