@@ -5,12 +5,18 @@
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" && export TMPDIR=/tmp
 OUT=gpurun_out/r03_aux
-rm -rf ${OUT}_kt ${OUT}_fetch ${OUT}_write
-python3 tools/bench_aux.py > ${OUT}_wall.jsonl 2> ${OUT}_wall.err
-for c in $(python3 tools/bench_aux.py --list); do
+# PART=1 | 2 profiles the first / second half of the cases (one gpurun call each); the report is folded from both afterwards
+PART=${PART:-0}
+ALL=($(python3 tools/bench_aux.py --list))
+H=$(( (${#ALL[@]} + 1) / 2 ))
+if [ "$PART" = 1 ]; then CASES=("${ALL[@]:0:$H}"); python3 tools/bench_aux.py > ${OUT}_wall.jsonl 2> ${OUT}_wall.err
+elif [ "$PART" = 2 ]; then CASES=("${ALL[@]:$H}")
+else CASES=("${ALL[@]}"); python3 tools/bench_aux.py > ${OUT}_wall.jsonl 2> ${OUT}_wall.err; fi
+for c in "${CASES[@]}"; do
+  rm -rf ${OUT}_kt/$c ${OUT}_fetch/$c ${OUT}_write/$c
   rocprofv3 --kernel-trace --output-format csv -d ${OUT}_kt/$c -- python3 tools/bench_aux.py --case $c > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d ${OUT}_fetch/$c -- python3 tools/bench_aux.py --case $c > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d ${OUT}_write/$c -- python3 tools/bench_aux.py --case $c > /dev/null 2>&1
   echo "profiled $c"
 done
-python3 tools/aux_report.py ${OUT}
+if [ "$PART" != 1 ]; then python3 tools/aux_report.py ${OUT}; fi

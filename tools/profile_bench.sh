@@ -6,7 +6,7 @@ O=gpurun_out/r03
 python3 bench.py > ${O}_bench_c2.json 2> ${O}_bench_c2.err
 python3 bench.py --config C3 > ${O}_bench_c3.json 2> ${O}_bench_c3.err
 python3 bench.py --config C4 --steps 5 --warmup 1 > ${O}_bench_c4.json 2> ${O}_bench_c4.err
-python3 bench.py --config C5 > ${O}_bench_c5_fp32.json 2> ${O}_bench_c5_fp32.err
+python3 bench.py --config C5 --train-precision fp32 > ${O}_bench_c5_fp32.json 2> ${O}_bench_c5_fp32.err
 python3 bench.py --config C5 --train-precision f16x3 > ${O}_bench_c5_f16x3.json 2> ${O}_bench_c5_f16x3.err
 python3 bench.py --precision fp32 --no-fp32-extra > ${O}_bench_c2_fp32.json 2> ${O}_bench_c2_fp32.err
 echo benches done
@@ -17,3 +17,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d ${O}_bench_writ
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d ${O}_bench_sq1 -- $B > ${O}_bench_sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d ${O}_bench_sq2 -- $B > ${O}_bench_sq2.log 2>&1
 python3 tools/rocprof_summarize.py ${O}_bench_pmc.json ${O}_bench_kt ${O}_bench_fetch ${O}_bench_write ${O}_bench_sq1 ${O}_bench_sq2
+python3 bench.py --config C5 --trainer autograd > ${O}_bench_c5_f16x3_autograd.json 2> ${O}_bench_c5_f16x3_autograd.err
+python3 tools/report_precision.py > ${O}_precision.log 2>&1
+python3 tools/bench_small_batch.py > ${O}_small_batch.jsonl 2> ${O}_small_batch.err
+rocprofv3 --kernel-trace --stats --output-format csv -d ${O}_c5_kt -- python3 bench.py --config C5 --no-cpu-baseline --steps 10 --warmup 2 > ${O}_c5_kt.log 2>&1
+echo profile_bench done

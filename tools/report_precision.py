@@ -1,5 +1,5 @@
 """Measured distance of each MFMA mode from the reference's golden maps and from the float64 truth, per golden case.
-Writes one JSON document (profiles/r02_precision.json); DESIGN.md section 3 quotes it and tests/test_gpu_parity.py takes
+Writes one JSON document (profiles/r03_precision.json); DESIGN.md section 3 quotes it and tests/test_gpu_parity.py takes
 its f16x3-vs-reference tolerance from the worst case."""
 import json
 import os
@@ -45,5 +45,5 @@ for case, wkey, r, sgs in CASES:
 out['worst'] = {k: max(c[k] for c in out['cases'].values()) for k in
                 ('fp32_vs_reference', 'f16x3_vs_reference', 'fp32_vs_fp64_truth', 'f16x3_vs_fp64_truth', 'reference_fp32_vs_fp64_truth')}
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'r02_precision.json'), 'w'), indent=1)
+json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'r03_precision.json'), 'w'), indent=1)
 print(json.dumps(out['worst']))
