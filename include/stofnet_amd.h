@@ -313,6 +313,17 @@ int stof_train_sweep_pack(const stof_net_desc* desc, const float* const* params_
 size_t stof_train_sweep_dump_floats(int64_t N, int64_t L);
 int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev, const float* x, const float* sgb_expand, float* dump,
                      float* y, int64_t N, int64_t L, void* stream);
+/* The data-gradient chain of the same step as ONE backward sweep (the mirror image of stof_train_sweep): from
+ * g6[N][L][64] = dL/d(conv12 output) (= stof_train_conv of conv_last's transposed weights on dL/dpred) it runs conv12^T,
+ * conv11^T .. conv2^T with the leaky-ReLU derivatives (read off the sign of the saved activations in fwd_dump = the dump
+ * stof_train_sweep wrote) and the residual additions of models/stofnet.py:51-62 reversed, and writes every layer's output for the weight-gradient
+ * kernels: dump tensor j (1..11; stof_train_sweep_dump_floats) = output of sweep layer j = conv(13-j)^T: j odd: dL/dx_k with
+ * k = (11-j)/2 (before the long-skip term), j even: dL/d(conv(12-j) output before its leaky ReLU).  blob: the eleven
+ * conv2..conv12 weights (device pointers, forward order) packed on the device by stof_train_sweep_bwd_pack into
+ * stof_train_sweep_blob_bytes bytes.                                                                                   */
+int stof_train_sweep_bwd_pack(const float* const* conv_weights_dev, void* blob_dev, void* stream);
+int stof_train_sweep_bwd(const stof_net_desc* desc, const void* blob_dev, const float* g6, const float* fwd_dump,
+                         float* dump, int64_t N, int64_t L, void* stream);
 /* Loss of main.py:228-232: target = amplitude * blur7(coords2mask(gt)) / max, loss = MSE + lambda * mean|pred|;
  * writes target[N*M], tmax[1], dpred[N*M] = grad_scale * dloss/dpred and loss[1] (double).  grad_scale is a power
  * of two (loss scaling: keeps the back-propagated values inside the fp16 range of the f16x3 mode); the weight-

@@ -106,6 +106,8 @@ _SIGNATURES = {
     'stof_train_sweep_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'stof_train_sweep_dump_floats': (_c.c_size_t, [_c.c_int64, _c.c_int64]),
     'stof_train_sweep': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
+    'stof_train_sweep_bwd_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'stof_train_sweep_bwd': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
     'stof_train_pool': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_void_p]),
     'stof_train_pool_bwd': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_void_p]),
     'stof_train_upsample_add': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_void_p]),

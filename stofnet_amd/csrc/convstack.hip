@@ -203,6 +203,10 @@ struct BodyParams {
     // residual add), 11 = conv12's; followed by >= 2 KiB the kernel may scribble on (rows that are padding)
     float* dump;
     long long dump_stride;        // floats per tensor = N * L * 64
+    // backward sweep: gin = gradient at conv12's output, channel-last [N][L][64]; fwd_dump = the forward sweep's dump, whose
+    // tensors 1, 3, .., 9 (outputs of conv2, 4, .., 10 after their leaky ReLU) give the leaky-ReLU derivatives by their sign
+    const float* gin;
+    const float* fwd_dump;
 };
 
 // RF = floats per activation row: ROWF (272 B) for the 32-wide MFMA shapes; 72 (288 B) for the 16x16x32 body, whose
@@ -222,9 +226,15 @@ struct BodyLds {
 
 constexpr int ROWF16 = 72;        // 288-byte rows of the 16x16x32 body (see BodyLds)
 
-template <int PREC, int S, int RING, int RAWRING, int SHAPE = 32, bool DUMP = false>
+// BWD: the data-gradient chain of the training step as the same sweep run backwards through the network (stof_train_sweep_bwd):
+// "layer 0" loads dL/dx6 rows from HBM instead of computing conv1, sweep layer j = 1..11 is the transposed convolution of
+// conv(13 - j): j = 1 plain, even j times the leaky-ReLU derivative of the saved activation (sign bytes), odd j >= 3 added to
+// the residual gradient in place; every layer's output goes to HBM for the weight-gradient kernels (DUMP); no conv_last.
+template <int PREC, int S, int RING, int RAWRING, int SHAPE = 32, bool DUMP = false, bool BWD = false>
 __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) {
     static_assert(!DUMP || SHAPE == 16, "the training dump lives in the 16x16x32 body");
+    static_assert(!BWD || DUMP, "the backward sweep's outputs are its dumps");
+    constexpr int NCHUNK_STEP = BWD ? 11 * BODY_CHUNKS_K7 : BODY_NCHUNK;      // weight chunks consumed per sweep step
     static_assert((RING & (RING - 1)) == 0 && (RAWRING & (RAWRING - 1)) == 0, "rings are powers of two");
     static_assert(S % 64 == 0 && S + 36 <= RING && S + 42 <= RAWRING, "ring must hold the live span");
     static_assert(SHAPE == 32 || (SHAPE == 16 && PREC == STOF_PREC_F16X3), "the 16x16x32 body is a split-fp16 kernel");
@@ -412,12 +422,35 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
         }
     };
     static_assert(S <= 240 && S > 160, "probe offsets {0, 80, 160, S-1} assume 160 < S <= 240");
-    if (tid < 4 && tid < L) {                                            // rows 0..3 precede the first fetch
-        int nw, tw;
-        vmap(n0, tid, nw, tw);
-        if (tw >= 0 && tw < Ltrue) rawr[tid] = p.x[(size_t)nw * Ltrue + tw];
+    if constexpr (!BWD) {
+        if (tid < 4 && tid < L) {                                        // rows 0..3 precede the first fetch
+            int nw, tw;
+            vmap(n0, tid, nw, tw);
+            if (tw >= 0 && tw < Ltrue) rawr[tid] = p.x[(size_t)nw * Ltrue + tw];
+        }
+        fetch_step(S, 0, 0);
     }
-    fetch_step(S, 0, 0);
+    // backward sweep, "layer 0": stream rows [rstart, rstart + S) of dL/dx6 (channel-last fp32 in HBM) into ring dst as split fp16;
+    // same thread mapping as x0_pass (4 channels x NIT consecutive rows), all loads issued before the first store
+    auto gin_pass = [&](char* dst, int rstart, int nR, int tR) {
+        constexpr int NIT = S / 16;
+        const int g0 = rstart + rl * NIT;
+        int nb, tb;
+        decode_row(nR, tR, rl * NIT, nb, tb);
+        float4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int g = g0 + it;
+            int t = tb + it, nl = nb;
+            if (t >= Lp) { t -= Lp; nl += 1; }
+            int nw, tw;
+            vmap(n0 + nl, t, nw, tw);
+            const bool ok = (g >= 0) && (g < gend) && (t < L) && (tw >= 0) && (tw < Ltrue);
+            v[it] = ok ? ld4(p.gin + ((size_t)nw * Ltrue + tw) * NF + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) store_act4<PREC>(dst + ((g0 + it) & (RING - 1)) * ROWB, 4 * cq, v[it]);
+    };
 
     // ---- weight fragments: registers, fetched two chunks ahead of use
     const uint4* const wbase = reinterpret_cast<const uint4*>(p.chunks) + mi * 64 + lane;
@@ -445,26 +478,27 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
         // The raw samples [F+4-S, F+4) and the SemiGlobalBlock rows of the windows that meet
         // [F-S, F) were fetched into registers one step ago (or by the prologue): land them in LDS,
         // then start the fetch for the next step so its latency hides behind this step's MFMAs.
-        if (tid < S) rawr[(F + 4 - S + tid) & (RAWRING - 1)] = raw_next;
-        if (sg_slot >= 0) sgl[sg_slot * NF + (tid & 63)] = sg_next;
-        {
+        if constexpr (!BWD) {
+            if (tid < S) rawr[(F + 4 - S + tid) & (RAWRING - 1)] = raw_next;
+            if (sg_slot >= 0) sgl[sg_slot * NF + (tid & 63)] = sg_next;
             int nN = nS, tN = tS + S;                     // decode of row F (first row of the next step)
             while (tN >= Lp) { tN -= Lp; nN += 1; }
             fetch_step(F + S, nN, tN);
         }
         __syncthreads();
         STAMP_ADD(0);                             // raw load + barrier
-        x0_pass(Xr, F - S, nS, tS, true);         // sweep layer 0
+        if constexpr (BWD) gin_pass(Xr, F - S, nS, tS);
+        else x0_pass(Xr, F - S, nS, tS, true);    // sweep layer 0
         STAMP_ADD(1);                             // x0 passes
         __syncthreads();
         STAMP_ADD(2);                             // barrier waits
 
         int c = 0;                                // chunk index within the step
-        for (int j = 1; j <= 12; ++j) {
+        for (int j = 1; j <= (BWD ? 11 : 12); ++j) {
             // waveform / time of the layer's first row R0 = F - S - lag (may precede the stream: n = -1)
             int nR = nS, tR = tS - layer_lag(j);
             while (tR < 0) { tR += Lp; nR -= 1; }
-            if (j == 11) {                        // long skip: seed the destination with x0
+            if (!BWD && j == 11) {                // long skip: seed the destination with x0
                 x0_pass(Yr, F - S - 33, nR, tR, false);
                 STAMP_ADD(1);
                 __syncthreads();
@@ -619,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                 // ds_reads of the NEXT chunk's activation fragments ride behind every third MFMA.  The VMEM groups pin the
                 // refills where they are written: left to itself the scheduler sinks them to just before their use.
                 auto do_chunk = [&](uint4 (&w)[FRAGS_PER_CHUNK], uint4 (&bcur)[NN][2], uint4 (&bnext)[NN][2], int cc) {
-                    const int c2 = (c + 2 >= BODY_NCHUNK) ? c + 2 - BODY_NCHUNK : c + 2;
+                    const int c2 = (c + 2 >= NCHUNK_STEP) ? c + 2 - NCHUNK_STEP : c + 2;
                     bload(bnext, cc + 1);          // past the layer's last chunk this reads rows nobody uses
                     mma_half(w[0], w[1], bcur, 0, cc == 0);
                     w[0] = wload(c2, 0);
@@ -642,7 +676,9 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                 bload(bf0, 0);
                 STAMP_ADD(3);                         // layer setup + first activation fragments
                 char* const dst = (j & 1) ? Yr : Xr;                // odd sweep layers write ring Y
-                const bool inplace = !(j & 1) || (j == 11);         // residual add: conv3,5,..,11 and conv12
+                // forward: residual add for conv3,5,..,11 and conv12, leaky ReLU for conv2,4,..,10; backward: j = 1 plain, even j
+                // times lrelu'(saved activation), odd j >= 3 added in place to the residual gradient
+                const bool inplace = BWD ? ((j & 1) && j >= 3) : (!(j & 1) || (j == 11));
                 // validity and LDS slot of the wave's row of N-tile n
                 auto row_of = [&](int n, bool& valid, int& slot, int& nw, int& tw, int& tk) {
                     const int off = 16 * (NN * ni + n) + i16;
@@ -657,6 +693,55 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                     // ---- main part chunk-major, then the last TAILC chunks tile-major: the epilogue of N-tile n-1 (residual add
                     // or leaky ReLU, validity, fp16 split, ring store: VALU + LDS work) is issued in the shadow of the MFMAs of
                     // N-tile n; only the last tile's epilogue stays exposed (1/6 of the layer's output, 1/3 with 32-row tiles).
+                    // Wave-uniform test on the wave's S/2-row span: inside one waveform (and, in segment mode, inside the segment's
+                    // own rows), nothing but real samples?  Then no row needs masking and the training dump addresses are affine.
+                    const int offw0 = 16 * NN * ni, gw0 = R0 + offw0;
+                    int nkw, tkw, nww, tww;
+                    decode_row(nR, tR, offw0, nkw, tkw);
+                    vmap(n0 + nkw, tkw, nww, tww);
+                    const bool span_ok = (gw0 >= 0) && (gw0 + 16 * NN - 1 < gend) && (tkw + 16 * NN - 1 < L) && (tww >= 0) &&
+                                         (tww + 16 * NN - 1 < Ltrue) && (tkw >= p.halo) && (tkw + 16 * NN - 1 < p.halo + p.seg_len);
+                    // training dump of this layer's output (tensor j): lane = 8 consecutive channels of its row of every N-tile;
+                    // a span with padding rows writes to the scratch tail instead and is dumped row by row afterwards
+                    float* const dumpj = DUMP ? p.dump + (size_t)j * p.dump_stride : nullptr;
+                    float* dlane = nullptr;
+                    long long dstep = 0;
+                    if constexpr (DUMP) {
+                        if (span_ok) {
+                            dlane = dumpj + ((size_t)nww * Ltrue + tww + i16) * NF + 32 * mi + 8 * q4;
+                            dstep = 16 * NF;
+                        } else {
+                            dlane = p.dump + 12 * p.dump_stride + 8 * lane;
+                        }
+                    }
+                    // backward, masked layers: the saved activation ys[k] (the forward dump's tensor 1 + 2 k) of the lane's 8 channels
+                    // of its row of every N-tile -- requested here, before the main chunks, so the loads have a whole layer's MFMAs
+                    // to arrive (the backward kernel has the registers: no x0 pass, no conv_last)
+                    const bool masked = BWD && !(j & 1);                       // conv(2k+3)^T output times lrelu'(ys[k]), k = 5 - j/2
+                    float4 ysv[BWD ? NN : 1][2];
+                    if constexpr (BWD) {
+#pragma unroll
+                        for (int n = 0; n < NN; ++n) ysv[n][0] = ysv[n][1] = make_float4(1.f, 1.f, 1.f, 1.f);
+                        if (masked) {
+                            const float* const ys = p.fwd_dump + (size_t)(1 + 2 * (5 - (j >> 1))) * p.dump_stride + 32 * mi + 8 * q4;
+                            if (span_ok) {
+                                const float* const src0 = ys + ((size_t)nww * Ltrue + tww + i16) * NF;
+#pragma unroll
+                                for (int n = 0; n < NN; ++n) { ysv[n][0] = ld4(src0 + (size_t)n * 16 * NF); ysv[n][1] = ld4(src0 + (size_t)n * 16 * NF + 4); }
+                            } else {
+#pragma unroll
+                                for (int n = 0; n < NN; ++n) {
+                                    bool valid;
+                                    int slot, nw, tw, tk;
+                                    row_of(n, valid, slot, nw, tw, tk);
+                                    if (valid) {
+                                        ysv[n][0] = ld4(ys + ((size_t)nw * Ltrue + tw) * NF);
+                                        ysv[n][1] = ld4(ys + ((size_t)nw * Ltrue + tw) * NF + 4);
+                                    }
+                                }
+                            }
+                        }
+                    }
 #ifndef STOF_TAILC
 #define STOF_TAILC 2
 #endif
@@ -681,31 +766,12 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                         acc[m][n] = mfma16(w[2 * m + (kk >= 4 ? 1 : 0)], b[(kk >> 1) == 1 ? 1 : 0], acc[m][n]);
                     };
                     const float one = opaque_one();
-                    // Wave-uniform test on the wave's S/2-row span: inside one waveform (and, in segment mode, inside the segment's
-                    // own rows), nothing but real samples?  Then no row needs masking and the training dump addresses are affine.
-                    const int offw0 = 16 * NN * ni, gw0 = R0 + offw0;
-                    int nkw, tkw, nww, tww;
-                    decode_row(nR, tR, offw0, nkw, tkw);
-                    vmap(n0 + nkw, tkw, nww, tww);
-                    const bool span_ok = (gw0 >= 0) && (gw0 + 16 * NN - 1 < gend) && (tkw + 16 * NN - 1 < L) && (tww >= 0) &&
-                                         (tww + 16 * NN - 1 < Ltrue) && (tkw >= p.halo) && (tkw + 16 * NN - 1 < p.halo + p.seg_len);
-                    // training dump of this layer's output (tensor j): lane = 8 consecutive channels of its row of every N-tile;
-                    // a span with padding rows writes to the scratch tail instead and is dumped row by row afterwards
-                    float* const dumpj = DUMP ? p.dump + (size_t)j * p.dump_stride : nullptr;
-                    float* dlane = nullptr;
-                    long long dstep = 0;
-                    if constexpr (DUMP) {
-                        if (span_ok) {
-                            dlane = dumpj + ((size_t)nww * Ltrue + tww + i16) * NF + 32 * mi + 8 * q4;
-                            dstep = 16 * NF;
-                        } else {
-                            dlane = p.dump + 12 * p.dump_stride + 8 * lane;
-                        }
-                    }
                     // The tail exists twice (in-place layers: old value + add; activation layers: leaky ReLU) so that the slices
                     // carry only the VALU work their layer needs.
-                    auto tail = [&](auto inplace_c) {
-                        constexpr bool INPL = decltype(inplace_c)::value;
+                    // kinds: 0 = residual add in place, 1 = leaky ReLU (forward), 2 = plain, 3 = times lrelu'(saved) (backward)
+                    auto tail = [&](auto kind_c) {
+                        constexpr int KIND = decltype(kind_c)::value;
+                        constexpr bool INPL = KIND == 0;
                         struct Epi { int slot; uint4 oh, ol; float v[4]; half2v h01, h23; unsigned hi[4], lo[4]; };
                         // The epilogue of one N-tile (8 consecutive channels of one row per lane) in 12 slices of <= 4 VALU
                         // instructions, one behind each MFMA of the NEXT tile:  0: LDS slot + (in-place) loads of the old hi | lo
@@ -739,10 +805,16 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                                     const half2v h = bits_h2(hw), l = bits_h2(lw);
                                     e.v[x0] = mix_add(l[0], mix_add(h[0], e.v[x0], one), one);
                                     e.v[x0 + 1] = mix_add(l[1], mix_add(h[1], e.v[x0 + 1], one), one);
-                                } else {
+                                } else if constexpr (KIND == 1) {
                                     // leaky_relu(v, 0.01) = max(v, 0.01 v) = med3(v, 0.01 v, huge): one op, where fmaxf costs a canonicalising v_max on top
                                     e.v[x0] = __builtin_amdgcn_fmed3f(e.v[x0], 0.01f * e.v[x0], 3.0e38f);
                                     e.v[x0 + 1] = __builtin_amdgcn_fmed3f(e.v[x0 + 1], 0.01f * e.v[x0 + 1], 3.0e38f);
+                                } else if constexpr (KIND == 3) {
+                                    // times lrelu'(saved activation): 1 where it was positive, 0.01 elsewhere
+                                    const float4 sv = ysv[n][m];
+                                    const float s0 = x0 == 0 ? sv.x : sv.z, s1 = x0 == 0 ? sv.y : sv.w;
+                                    e.v[x0] = s0 > 0.f ? e.v[x0] : 0.01f * e.v[x0];
+                                    e.v[x0 + 1] = s1 > 0.f ? e.v[x0 + 1] : 0.01f * e.v[x0 + 1];
                                 }
                             } else if (st == 3) {
                                 if constexpr (DUMP) st4(dlane + n * dstep + 4 * m, make_float4(e.v[0], e.v[1], e.v[2], e.v[3]));
@@ -779,7 +851,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                                 else if (n > 0) epi_slice(ep[(n - 1) & 1], n - 1, k);
                                 if (n == NN - 1 && (k == 5 || k == 11)) {   // last use of wf[0] / wf[1]: refill with the next layer's first chunks
                                     const int q = k == 5 ? 0 : 1;
-                                    const int c2 = (c + 2 + q >= BODY_NCHUNK) ? c + 2 + q - BODY_NCHUNK : c + 2 + q;
+                                    const int c2 = (c + 2 + q >= NCHUNK_STEP) ? c + 2 + q - NCHUNK_STEP : c + 2 + q;
 #pragma unroll
                                     for (int f = 0; f < FRAGS_PER_CHUNK; ++f) wf[q][f] = wload(c2, f);
                                 }
@@ -805,8 +877,11 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
 #pragma unroll
                         for (int k = 1; k < 12; ++k) epi_slice(ep[(NN - 1) & 1], NN - 1, k);
                     };
-                    if (inplace) tail(std::true_type{});
-                    else tail(std::false_type{});
+                    if (inplace) tail(std::integral_constant<int, 0>{});
+                    else if constexpr (BWD) {
+                        if (j == 1) tail(std::integral_constant<int, 2>{});
+                        else tail(std::integral_constant<int, 3>{});
+                    } else tail(std::integral_constant<int, 1>{});
                     // Rows outside [0, L) of their waveform (gap rows, stream ends, segment padding) must read as zeros for the
                     // next layer (= its zero padding).  When the wave's span lies inside one waveform nothing is to do (the
                     // common case); otherwise the lanes of padding rows overwrite what the branch-free tail stored (same lane,
@@ -1629,6 +1704,7 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         bp.N = (int)nb; bp.L = (int)L; bp.r = r; bp.P = (int)P; bp.rem_half = (int)(rem / 2);
         bp.stamps = nullptr;
         bp.dump = nullptr; bp.dump_stride = 0;
+        bp.gin = nullptr; bp.fwd_dump = nullptr;
         bp.status = status;
         bp.run_if = run_if;
         // Cut every waveform into 2^k segments (each swept with +-38 rows of real context, the receptive field of
@@ -1879,6 +1955,36 @@ extern "C" size_t stof_train_sweep_dump_floats(int64_t N, int64_t L) {
     return (size_t)12 * N * L * NF + 1024;
 }
 
+namespace {
+// shared launch geometry of the training sweeps (as the inference launch: segments keep the CUs busy for small batches)
+int train_sweep_geometry(const stof_net_desc* desc, BodyParams& bp, int64_t N, int64_t L, int64_t* wgs_out) {
+    const int ncu = device_cu_count();
+    bp.nseg_log2 = 0;
+    int64_t best = -1;
+    for (int k = 0; k <= 5; ++k) {
+        const int64_t ns = (int64_t)1 << k;
+        if (k > 0 && L / ns < BODY_S / 2) break;
+        const int64_t lv = (L + ns - 1) / ns + (k > 0 ? 76 : 0);
+        const int64_t nvk = N * ns;
+        const int64_t w = nvk < ncu ? nvk : ncu;
+        const int64_t per = (nvk + w - 1) / w;
+        const int64_t steps = (per * (lv + GAP) - GAP + LAG_LAST + BODY_S - 1) / BODY_S;
+        if (best < 0 || steps < best) { best = steps; bp.nseg_log2 = k; }
+    }
+    if (desc->seg_policy > 0) bp.nseg_log2 = desc->seg_policy - 1;
+    const int64_t nseg = (int64_t)1 << bp.nseg_log2;
+    bp.seg_len = (int)((L + nseg - 1) / nseg);
+    bp.halo = nseg > 1 ? 38 : 0;
+    const int64_t nv = N * nseg;
+    if ((int64_t)(bp.seg_len + 2 * bp.halo + GAP) * nv > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    bp.N = (int)nv;
+    int64_t wgs = nv < ncu ? nv : ncu;
+    bp.wf_per_wg = (int)((nv + wgs - 1) / wgs);
+    *wgs_out = (nv + bp.wf_per_wg - 1) / bp.wf_per_wg;
+    return STOF_OK;
+}
+}  // namespace
+
 extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev, const float* x, const float* sgb_expand,
                                 float* dump, float* y, int64_t N, int64_t L, void* stream_) {
     if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
@@ -1894,7 +2000,7 @@ extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev,
     if ((L + GAP) * N > 0x7fffffffLL || N * L * NF > 0x7fffffffffLL) return STOF_ERR_UNSUPPORTED;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using Lds16 = BodyLds<BODY_S, BODY_RING, BODY_RAWRING, ROWF16>;
-    auto kernel = &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true>;
+    auto kernel = &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, false>;
     static LdsLimitOnce lds;
     if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)Lds16::BYTES)) return st;
     const float* base = static_cast<const float*>(blob_dev);
@@ -1906,32 +2012,74 @@ extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev,
     bp.stamps = nullptr; bp.status = nullptr; bp.run_if = nullptr;
     bp.onset_ws = nullptr; bp.onset_slots = 0; bp.onset_seg_slots = 0;
     bp.dump = dump; bp.dump_stride = (long long)N * L * NF;
-    // segments as in the inference launch: few waveforms per CU leave work-groups idle otherwise
-    const int ncu = device_cu_count();
-    bp.nseg_log2 = 0;
-    {
-        int64_t best = -1;
-        for (int k = 0; k <= 5; ++k) {
-            const int64_t ns = (int64_t)1 << k;
-            if (k > 0 && L / ns < BODY_S / 2) break;
-            const int64_t lv = (L + ns - 1) / ns + (k > 0 ? 76 : 0);
-            const int64_t nvk = N * ns;
-            const int64_t w = nvk < ncu ? nvk : ncu;
-            const int64_t per = (nvk + w - 1) / w;
-            const int64_t steps = (per * (lv + GAP) - GAP + LAG_LAST + BODY_S - 1) / BODY_S;
-            if (best < 0 || steps < best) { best = steps; bp.nseg_log2 = k; }
-        }
+    bp.gin = nullptr; bp.fwd_dump = nullptr;
+    int64_t wgs = 0;
+    if (int st = train_sweep_geometry(desc, bp, N, L, &wgs)) return st;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), Lds16::BYTES, stream, bp);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+// ---- backward sweep: the eleven data-gradient convolutions conv12^T .. conv2^T of the training step in one launch
+namespace {
+struct SweepPackBwdArgs {
+    const float* w[11];       // conv2.weight .. conv12.weight (forward order), each (64, 64, 7)
+    float* blob;              // [c1 640 unused][bias 832 zeros][BODY_NCHUNK * BODY_CHUNK_F]
+};
+__global__ __launch_bounds__(256) void sweep_pack_bwd_kernel(const SweepPackBwdArgs a) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    const long long n_head = 640 + 13 * 64, n_body = (long long)BODY_NCHUNK * BODY_CHUNK_F * 2;
+    if (i < n_head) { a.blob[i] = 0.f; return; }
+    const long long k = i - n_head;
+    if (k >= n_body) return;
+    _Float16* const body = reinterpret_cast<_Float16*>(a.blob + n_head);
+    const int e = (int)(k & 7), lane = (int)((k >> 3) & 63), blk = (int)((k >> 9) & 1), frag = (int)((k >> 10) & 3);
+    const int c = (int)(k >> 12);
+    if (c >= 11 * BODY_CHUNKS_K7) { body[k] = (_Float16)0.f; return; }
+    const int j = 1 + c / BODY_CHUNKS_K7, cc = c % BODY_CHUNKS_K7;      // sweep layer j = conv(13 - j)^T
+    const int tap = cc >> 1, hh = cc & 1, m = frag >> 1, part = frag & 1, i16 = lane & 15, q = lane >> 4;
+    const int arow = body16_out_channel(blk, m, i16);                    // output of the transposed conv = input channel c of conv(13 - j)
+    const int b = 32 * hh + 8 * q + e;                                   // contraction index = its output channel o
+    const float v = a.w[11 - j][((size_t)b * NF + arow) * 7 + (6 - tap)];
+    const _Float16 hi = (_Float16)v;
+    body[k] = part == 0 ? hi : (_Float16)(v - (float)hi);
+}
+}  // namespace
+
+extern "C" int stof_train_sweep_bwd_pack(const float* const* conv_weights_dev, void* blob_dev, void* stream) {
+    if (!conv_weights_dev || !blob_dev) return STOF_ERR_BAD_ARG;
+    SweepPackBwdArgs a;
+    for (int i = 0; i < 11; ++i) {
+        if (!conv_weights_dev[i]) return STOF_ERR_BAD_ARG;
+        a.w[i] = conv_weights_dev[i];
     }
-    if (desc->seg_policy > 0) bp.nseg_log2 = desc->seg_policy - 1;
-    const int64_t nseg = (int64_t)1 << bp.nseg_log2;
-    bp.seg_len = (int)((L + nseg - 1) / nseg);
-    bp.halo = nseg > 1 ? 38 : 0;
-    const int64_t nv = N * nseg;
-    if ((int64_t)(bp.seg_len + 2 * bp.halo + GAP) * nv > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
-    bp.N = (int)nv;
-    int64_t wgs = nv < ncu ? nv : ncu;
-    bp.wf_per_wg = (int)((nv + wgs - 1) / wgs);
-    wgs = (nv + bp.wf_per_wg - 1) / bp.wf_per_wg;
+    a.blob = static_cast<float*>(blob_dev);
+    const long long total = 640 + 13 * 64 + (long long)BODY_NCHUNK * BODY_CHUNK_F * 2;
+    hipLaunchKernelGGL(sweep_pack_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_sweep_bwd(const stof_net_desc* desc, const void* blob_dev, const float* g6, const float* fwd_dump,
+                                    float* dump, int64_t N, int64_t L, void* stream_) {
+    if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
+    if (N == 0 || L == 0) return STOF_OK;
+    if (!blob_dev || !g6 || !fwd_dump || !dump) return STOF_ERR_BAD_ARG;
+    if ((L + GAP) * N > 0x7fffffffLL || N * L * NF > 0x7fffffffffLL) return STOF_ERR_UNSUPPORTED;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    using Lds16 = BodyLds<BODY_S, BODY_RING, BODY_RAWRING, ROWF16>;
+    auto kernel = &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, true>;
+    static LdsLimitOnce lds;
+    if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)Lds16::BYTES)) return st;
+    const float* base = static_cast<const float*>(blob_dev);
+    BodyParams bp;
+    bp.x = nullptr; bp.sgb = nullptr; bp.y = nullptr;
+    bp.c1 = base; bp.bias = base + 640; bp.chunks = base + 640 + 13 * 64; bp.last16 = nullptr;
+    bp.L = (int)L; bp.r = 1; bp.P = 0; bp.rem_half = 0;
+    bp.stamps = nullptr; bp.status = nullptr; bp.run_if = nullptr;
+    bp.onset_ws = nullptr; bp.onset_slots = 0; bp.onset_seg_slots = 0;
+    bp.dump = dump; bp.dump_stride = (long long)N * L * NF;
+    bp.gin = g6; bp.fwd_dump = fwd_dump;
+    int64_t wgs = 0;
+    if (int st = train_sweep_geometry(desc, bp, N, L, &wgs)) return st;
     hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), Lds16::BYTES, stream, bp);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }

@@ -9,6 +9,7 @@ the fused inference sweep does not apply).  PyTorch only owns the device buffers
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -18,6 +19,7 @@ from . import _lib
 from .stofnet import StofNet
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+BODY_CONVS = tuple(f'conv{i}' for i in range(2, 13))
 
 
 def gaussian_kernel(size, sigma=1.0):
@@ -110,7 +112,9 @@ class TrainEngine:
         head = ('semi_global_block.',) if use_sweep else ('conv', 'semi_global_block.')        # layers that still run one by one
         fwd = {k[:-7]: self._repack(v, False) for k, v in p.items()
                if k.endswith('.weight') and k != 'conv1.weight' and k.startswith(head)}
-        bwd = {k[:-7]: self._repack(v, True) for k, v in p.items() if k.endswith('.weight') and k != 'conv1.weight'} if keep else None
+        sweep_bwd = use_sweep and os.environ.get('STOF_TRAIN_SWEEP_BWD', '1') != '0'       # conv2..conv12 data gradients: one sweep too
+        bwd = {k[:-7]: self._repack(v, True) for k, v in p.items() if k.endswith('.weight') and k != 'conv1.weight'
+               and not (sweep_bwd and k[:-7] in BODY_CONVS)} if keep else None
         a1 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
         _lib.check(lib.stof_train_conv1(_lib.ptr(x), _lib.ptr(p['conv1.weight']), _lib.ptr(p['conv1.bias']), _lib.ptr(a1),
                                         n, L, st), 'stof_train_conv1')
@@ -142,7 +146,7 @@ class TrainEngine:
             xs = [t[0]] + [t[2 + 2 * k] for k in range(5)]
             ys = [t[1 + 2 * k] for k in range(5)]
             saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=t[11], bwd=bwd, n=n, L=L, P=P, rem=rem,
-                         _dump=dump)
+                         _dump=dump, desc=desc, wdev=[p[f'conv{i}.weight'] for i in range(2, 13)])
             return z, saved
         if self.sgb:
             x0, c, pooled, arg, e = self._sgb_forward(a1, fwd[sg + 'contract_conv'], p[sg + 'contract_conv.bias'],
@@ -209,13 +213,31 @@ class TrainEngine:
         self._wgrad(x6, dz, 'conv_last', 64, r, 3)
         g6 = self._conv(dz, bwd['conv_last'], None, r, 64, 3)
         self._wgrad(xs[5], g6, 'conv12', 64, 64, 7)
-        gg = self._conv(g6, bwd['conv12'], None, 64, 64, 7)                       # d/dx5
-        for k in range(4, -1, -1):
-            nb, na = f'conv{2 * k + 3}', f'conv{2 * k + 2}'
-            self._wgrad(ys[k], gg, nb, 64, 64, 7)
-            u = self._conv(gg, bwd[nb], None, 64, 64, 7, ACT_LRELU, saved=ys[k])  # d/d(pre-activation of conv_a)
-            self._wgrad(xs[k], u, na, 64, 64, 7)
-            gg = self._conv(u, bwd[na], None, 64, 64, 7, residual=gg)             # d/dx_k
+        if saved.get('_dump') is not None and 'conv12' not in bwd:
+            # the eleven data-gradient convolutions conv12^T .. conv2^T as ONE backward sweep (stof_train_sweep_bwd), then the
+            # weight gradients from its dumps: tensor j odd = dL/dx_k, k = (11 - j) / 2; j even = dL/d(pre-activation of conv(12 - j))
+            import ctypes
+            nbytes = lib.stof_train_sweep_blob_bytes(ctypes.byref(saved['desc']))
+            if getattr(self, '_sweep_blob_bwd', None) is None or self._sweep_blob_bwd.numel() < nbytes:
+                self._sweep_blob_bwd = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            arr = (ctypes.c_void_p * 11)(*[_lib.ptr(w.contiguous()) for w in saved['wdev']])
+            _lib.check(lib.stof_train_sweep_bwd_pack(arr, _lib.ptr(self._sweep_blob_bwd), st), 'stof_train_sweep_bwd_pack')
+            dumpb = torch.empty(lib.stof_train_sweep_dump_floats(n, L), dtype=torch.float32, device=self.dev)
+            _lib.check(lib.stof_train_sweep_bwd(ctypes.byref(saved['desc']), _lib.ptr(self._sweep_blob_bwd), _lib.ptr(g6), _lib.ptr(saved['_dump']),
+                                                _lib.ptr(dumpb), n, L, st), 'stof_train_sweep_bwd')
+            T = dumpb[:12 * n * L * 64].view(12, n, L, 64)
+            for k in range(4, -1, -1):
+                self._wgrad(ys[k], T[9 - 2 * k], f'conv{2 * k + 3}', 64, 64, 7)        # g_{k+1} = T[11 - 2 (k + 1)]
+                self._wgrad(xs[k], T[10 - 2 * k], f'conv{2 * k + 2}', 64, 64, 7)       # u_k
+            gg = T[11]                                                                   # dL/dx_0 without the long skip
+        else:
+            gg = self._conv(g6, bwd['conv12'], None, 64, 64, 7)                       # d/dx5
+            for k in range(4, -1, -1):
+                nb, na = f'conv{2 * k + 3}', f'conv{2 * k + 2}'
+                self._wgrad(ys[k], gg, nb, 64, 64, 7)
+                u = self._conv(gg, bwd[nb], None, 64, 64, 7, ACT_LRELU, saved=ys[k])  # d/d(pre-activation of conv_a)
+                self._wgrad(xs[k], u, na, 64, 64, 7)
+                gg = self._conv(u, bwd[na], None, 64, 64, 7, residual=gg)             # d/dx_k
         g_x0 = self._add(gg, g6)                                                  # long skip res1 (models/stofnet.py:62)
         if self.sgb and P:
             e, pooled, arg, c = saved['e'], saved['pooled'], saved['arg'], saved['c']
