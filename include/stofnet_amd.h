@@ -291,8 +291,17 @@ int stof_train_conv1_wgrad(const float* x, const float* g, const float* saved, f
  * ABI 3: `scale` is an argument (ABI 2 fixed it at 80, the value of every shipped checkpoint).             */
 int stof_train_pool(const float* c, float* pooled, uint8_t* arg, int64_t N, int64_t L, int64_t P, int32_t C,
                     int32_t scale, void* stream);
-int stof_train_pool_bwd(const float* gpool, const uint8_t* arg, const float* c, float* gc, int64_t N, int64_t L,
-                        int64_t P, int32_t C, int32_t scale, void* stream);
+/* pool backward: `c` (the pre-pool activation) may be NULL when `pooled` is given -- the activation at the arg-max IS the
+ * pooled value, which is all the leaky-ReLU derivative needs (the fused forward below never materialises c). */
+int stof_train_pool_bwd(const float* gpool, const uint8_t* arg, const float* c, const float* pooled, float* gc, int64_t N,
+                        int64_t L, int64_t P, int32_t C, int32_t scale, void* stream);
+/* Training forward of the SemiGlobalBlock's contracting path at sample_scale 80, split-fp16: relu(conv1) -> contract_conv ->
+ * lrelu -> MaxPool1d(80) fused as in inference (models/stofnet.py:45,100-103; the [N, L, 512] activation never reaches HBM):
+ * pooled[N][P][512] and arg[N][P][512] = row offset of each window's FIRST maximum (torch's max_pool1d backward routing).
+ * The four parameter tensors are device pointers; blob_dev = stof_train_sgb_blob_bytes() bytes of scratch the call packs. */
+size_t stof_train_sgb_blob_bytes(void);
+int stof_train_sgb_contract_pool(const float* conv1_w, const float* conv1_b, const float* contract_w, const float* contract_b,
+                                 void* blob_dev, const float* x, float* pooled, uint8_t* arg, int64_t N, int64_t L, void* stream);
 int stof_train_upsample_add(const float* a, const float* e, float* out, int64_t N, int64_t L, int64_t P,
                             int32_t rem_half, int32_t scale, void* stream);
 int stof_train_upsample_bwd(const float* g, const float* e, float* ge, int64_t N, int64_t L, int64_t P,

@@ -1314,10 +1314,12 @@ struct SgbParams {
     const float* chunks;   // [SGB_NCHUNK][SGB_CHUNK_F]
     int N, L, P, tiles_per_wf;
     const int* run_if;     // as BodyParams::run_if
+    unsigned char* arg;    // training (ARG): [N][P][512] row offset (0..79) of the window's FIRST maximum, for the pool's backward
 };
 
-template <int PREC, int NW, int SHAPE = 32>
+template <int PREC, int NW, int SHAPE = 32, bool ARG = false>
 __global__ __launch_bounds__(256, SGB_WAVES_PER_SIMD) void sgb_contract_pool_kernel(const SgbParams p) {
+    static_assert(!ARG || SHAPE == 16, "the arg-max output lives in the 16x16x32 form");
     static_assert(NW % 2 == 0, "80*NW must be a multiple of 32");
     static_assert(SHAPE == 32 || (SHAPE == 16 && PREC == STOF_PREC_F16X3), "the 16x16x32 form is a split-fp16 kernel");
     constexpr int ROWS = SGB_SCALE * NW;          // output rows of the tile
@@ -1456,12 +1458,38 @@ __global__ __launch_bounds__(256, SGB_WAVES_PER_SIMD) void sgb_contract_pool_ker
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
                     float mval = -INFINITY;
+                    if constexpr (ARG) {
+                        // training: the window's FIRST maximum and its row (torch's max_pool1d backward routes the gradient there);
+                        // bias and leaky ReLU are strictly increasing, so the arg-max of the accumulators is the arg-max of the
+                        // activation.  A lane's rows 16 m + 4 q4 + e ascend with (m, e); across the four q4 lanes the larger value
+                        // wins and equal values go to the smaller row.
+                        int bi = 0;
 #pragma unroll
-                    for (int m = 0; m < MW; ++m)
+                        for (int m = 0; m < MW; ++m)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) mval = fmaxf(mval, acc[w][m][nt][e]);
-                    mval = fmaxf(mval, __shfl_xor(mval, 16));
-                    mval = fmaxf(mval, __shfl_xor(mval, 32));
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = acc[w][m][nt][e];
+                                const bool up = v > mval;
+                                mval = up ? v : mval;
+                                bi = up ? 16 * m + 4 * q4 + e : bi;
+                            }
+#pragma unroll
+                        for (int off = 16; off <= 32; off <<= 1) {
+                            const float ov = __shfl_xor(mval, off);
+                            const int oi = __shfl_xor(bi, off);
+                            const bool take = (ov > mval) || (ov == mval && oi < bi);
+                            mval = take ? ov : mval;
+                            bi = take ? oi : bi;
+                        }
+                        if (q4 == 0 && w0 + w < p.P) p.arg[((size_t)n * p.P + w0 + w) * NF_SGB + oc] = (unsigned char)bi;
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MW; ++m)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) mval = fmaxf(mval, acc[w][m][nt][e]);
+                        mval = fmaxf(mval, __shfl_xor(mval, 16));
+                        mval = fmaxf(mval, __shfl_xor(mval, 32));
+                    }
                     mval += bias;
                     mval = mval > 0.f ? mval : 0.01f * mval;
                     if (q4 == 0 && w0 + w < p.P)
@@ -1681,6 +1709,7 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
             sp.N = (int)nb; sp.L = (int)L; sp.P = (int)P;
             sp.tiles_per_wf = (int)((P + SGB_NW - 1) / SGB_NW);
             sp.run_if = run_if;
+            sp.arg = nullptr;
             if (body16)
                 hipLaunchKernelGGL((sgb_contract_pool_kernel<PREC, SGB_NW, SHAPE_FAST>), dim3((unsigned)(nb * sp.tiles_per_wf)),
                                    dim3(256), sgb_bytes, stream, sp);
@@ -2016,6 +2045,65 @@ extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev,
     int64_t wgs = 0;
     if (int st = train_sweep_geometry(desc, bp, N, L, &wgs)) return st;
     hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), Lds16::BYTES, stream, bp);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+// ---- training forward of the SemiGlobalBlock's contracting path: relu(conv1) -> contract conv -> lrelu -> max-pool(80) fused as in
+// inference (the [N, L, 512] activation never reaches HBM), plus the pool's arg-max for the backward pass
+namespace {
+struct SgbPackArgs {
+    const float* c1w; const float* c1b; const float* cw; const float* cb;     // conv1 (64,1,9), (64); contract_conv (512,64,5), (512)
+    float* blob;              // [c1 640][cbias 512][SGB_NCHUNK * SGB_CHUNK_F]
+};
+__global__ __launch_bounds__(256) void sgb_pack_kernel(const SgbPackArgs a) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    const long long n_c1 = 640, n_cb = NF_SGB, n_body = (long long)SGB_NCHUNK * SGB_CHUNK_F * 2;
+    if (i < n_c1) {
+        const int c = (int)(i / 10), t = (int)(i % 10);
+        a.blob[i] = t < 9 ? a.c1w[c * 9 + t] : a.c1b[c];
+        return;
+    }
+    long long k = i - n_c1;
+    if (k < n_cb) { a.blob[n_c1 + k] = a.cb[k]; return; }
+    k -= n_cb;
+    if (k >= n_body) return;
+    // half index -> (chunk = (ocb, tap, hh), frag, tile, lane, e), the order of pack_chunk16_sgb (pack_weights.cpp)
+    const int e = (int)(k & 7), lane = (int)((k >> 3) & 63), tile = (int)((k >> 9) & 3), frag = (int)((k >> 11) & 3);
+    const int c = (int)(k >> 13);
+    const int hh = c & 1, tap = (c >> 1) % 5, ocb = c / 10;
+    const int nt = frag >> 1, part = frag & 1, j = lane & 15, q = lane >> 4;
+    const int o = 128 * ocb + 32 * tile + 16 * nt + j;
+    const float v = a.cw[((size_t)o * NF + 32 * hh + 8 * q + e) * 5 + tap];
+    const _Float16 hi = (_Float16)v;
+    reinterpret_cast<_Float16*>(a.blob + n_c1 + n_cb)[k] = part == 0 ? hi : (_Float16)(v - (float)hi);
+}
+}  // namespace
+
+extern "C" size_t stof_train_sgb_blob_bytes(void) { return (640 + NF_SGB + (size_t)SGB_NCHUNK * SGB_CHUNK_F) * sizeof(float); }
+
+extern "C" int stof_train_sgb_contract_pool(const float* conv1_w, const float* conv1_b, const float* contract_w, const float* contract_b,
+                                            void* blob_dev, const float* x, float* pooled, uint8_t* arg, int64_t N, int64_t L,
+                                            void* stream_) {
+    if (N < 0 || L < 0) return STOF_ERR_BAD_ARG;
+    const int64_t P = L / SGB_SCALE;
+    if (L > 0 && P == 0) return STOF_ERR_POOL_EMPTY;
+    if (N == 0 || L == 0) return STOF_OK;
+    if (!conv1_w || !conv1_b || !contract_w || !contract_b || !blob_dev || !x || !pooled || !arg) return STOF_ERR_BAD_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SgbPackArgs a;
+    a.c1w = conv1_w; a.c1b = conv1_b; a.cw = contract_w; a.cb = contract_b; a.blob = static_cast<float*>(blob_dev);
+    const long long total = 640 + NF_SGB + (long long)SGB_NCHUNK * SGB_CHUNK_F * 2;
+    hipLaunchKernelGGL(sgb_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    auto kernel = &sgb_contract_pool_kernel<STOF_PREC_F16X3, SGB_NW, 16, true>;
+    static LdsLimitOnce lds;
+    if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)sgb_lds_bytes(ROWF16))) return st;
+    SgbParams sp;
+    sp.x = x; sp.pooled = pooled; sp.c1 = a.blob; sp.cbias = a.blob + 640; sp.chunks = a.blob + 640 + NF_SGB;
+    sp.N = (int)N; sp.L = (int)L; sp.P = (int)P;
+    sp.tiles_per_wf = (int)((P + SGB_NW - 1) / SGB_NW);
+    sp.run_if = nullptr; sp.arg = arg;
+    if (N * sp.tiles_per_wf > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(N * sp.tiles_per_wf)), dim3(256), sgb_lds_bytes(ROWF16), stream, sp);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

@@ -894,7 +894,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 
 // gc[N][L][C] = 0 except gc[n][80w + arg][ch] = gpool[n][w][ch] * lrelu'(c at that position)
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ gpool, const unsigned char* __restrict__ arg,
-                                                       const float* __restrict__ c, float* __restrict__ gc,
+                                                       const float* __restrict__ c, const float* __restrict__ pooled, float* __restrict__ gc,
                                                        int N, int L, int P, int C, int S) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= (long long)N * P * C) return;
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     const int w = (int)(nw % P);
     const long long n = nw / P;
     const long long pos = (n * L + (long long)w * S + arg[i]) * C + ch;
-    const float s = c[pos];
+    const float s = pooled != nullptr ? pooled[i] : c[pos];       // the activation at the arg-max IS the pooled value
     gc[pos] = s > 0.f ? gpool[i] : 0.01f * gpool[i];
 }
 
@@ -1214,15 +1214,15 @@ extern "C" int stof_train_pool(const float* c, float* pooled, uint8_t* arg, int6
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
-extern "C" int stof_train_pool_bwd(const float* gpool, const uint8_t* arg, const float* c, float* gc, int64_t N, int64_t L,
-                                   int64_t P, int32_t C, int32_t scale, void* stream) {
+extern "C" int stof_train_pool_bwd(const float* gpool, const uint8_t* arg, const float* c, const float* pooled, float* gc,
+                                   int64_t N, int64_t L, int64_t P, int32_t C, int32_t scale, void* stream) {
     if (N < 0 || L < 0 || P < 0 || C < 1 || scale < 1 || scale > 256 || P * scale > L) return STOF_ERR_BAD_ARG;
     if (N * L == 0) return STOF_OK;
-    if (!gpool || !arg || !c || !gc) return STOF_ERR_BAD_ARG;
+    if (!gpool || !arg || (!c && !pooled) || !gc) return STOF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(gc, 0, (size_t)N * L * C * sizeof(float), s) != hipSuccess) return STOF_ERR_HIP;
     if (N * P > 0)
-        hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for(N * P * C)), dim3(256), 0, s, gpool, arg, c, gc, (int)N, (int)L,
+        hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for(N * P * C)), dim3(256), 0, s, gpool, arg, c, c ? nullptr : pooled, gc, (int)N, (int)L,
                            (int)P, C, scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }

@@ -122,7 +122,19 @@ class TrainEngine:
         if use_sweep:
             # SemiGlobalBlock up to the expand conv on the layer kernels (the backward pass needs c / pooled / arg); its
             # up-sampled map is added inside the sweep, which recomputes relu(conv1) from x
-            if self.sgb:
+            if self.sgb and os.environ.get('STOF_TRAIN_SGB_FUSED', '1') != '0':
+                # contract conv + lrelu + max-pool fused as in inference (no [N, L, 512] tensor), with the pool's arg-max
+                pooled = torch.empty((n, P, cm), dtype=torch.float32, device=self.dev)
+                arg = torch.empty((n, P, cm), dtype=torch.uint8, device=self.dev)
+                if getattr(self, '_sgb_blob', None) is None:
+                    self._sgb_blob = torch.empty(lib.stof_train_sgb_blob_bytes(), dtype=torch.uint8, device=self.dev)
+                _lib.check(lib.stof_train_sgb_contract_pool(_lib.ptr(p['conv1.weight'].contiguous()), _lib.ptr(p['conv1.bias'].contiguous()),
+                                                            _lib.ptr(p[sg + 'contract_conv.weight'].contiguous()),
+                                                            _lib.ptr(p[sg + 'contract_conv.bias'].contiguous()), _lib.ptr(self._sgb_blob),
+                                                            _lib.ptr(x), _lib.ptr(pooled), _lib.ptr(arg), n, L, st),
+                           'stof_train_sgb_contract_pool')
+                e = self._conv(pooled, fwd[sg + 'expand_conv'], p[sg + 'expand_conv.bias'], cm, 64, 5, ACT_LRELU)
+            elif self.sgb:
                 c, pooled, arg, e = self._sgb_head(a1, fwd[sg + 'contract_conv'], p[sg + 'contract_conv.bias'],
                                                    fwd[sg + 'expand_conv'], p[sg + 'expand_conv.bias'])
             desc = _lib.NetDesc(int(r), 80 if self.sgb else 1, _lib.PREC_F16X3, 0)
@@ -247,8 +259,8 @@ class TrainEngine:
                        'stof_train_upsample_bwd')
             self._wgrad(pooled, ge, sg + 'expand_conv', cm, 64, 5)
             gpool = self._conv(ge, bwd[sg + 'expand_conv'], None, 64, cm, 5)
-            gc = torch.empty_like(c)
-            _lib.check(lib.stof_train_pool_bwd(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(c), _lib.ptr(gc), n, L, P, cm, S, st),
+            gc = torch.empty((n, L, cm), dtype=torch.float32, device=self.dev)
+            _lib.check(lib.stof_train_pool_bwd(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(c), _lib.ptr(pooled), _lib.ptr(gc), n, L, P, cm, S, st),
                        'stof_train_pool_bwd')
             self._wgrad(a1, gc, sg + 'contract_conv', 64, cm, 5)
             g_a1 = self._conv(gc, bwd[sg + 'contract_conv'], None, cm, 64, 5, residual=g_x0)
