@@ -789,10 +789,6 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
                                 *reinterpret_cast<uint4*>(dst + e.slot + 128) = make_uint4(e.lo[0], e.lo[1], e.lo[2], e.lo[3]);
                                 return;
                             }
-#ifdef STOF_TAIL_SKIP_VALU
-                            if (k == 1) for (int x = 0; x < 4; ++x) { e.hi[x] = 0u; e.lo[x] = 0u; }      // timing experiment only: wrong results
-                            return;
-#endif
                             const int m = (k - 1) / 5, st = (k - 1) % 5;
                             if (st == 0) {
 #pragma unroll
