@@ -235,6 +235,16 @@ int stof_toa_detect(const float* frame, int64_t N, int64_t L, int32_t grad_step,
                     float threshold, int32_t ival_min, int32_t ival_max, int64_t echo_max, float* echoes,
                     int64_t cap, float* reduced, int32_t* counts, int32_t* flags, float* env_out, void* stream);
 
+/* Pre-pass of the default threshold (Q7, models/gradpeak.py:18) on WAVEFORMS frame[N, L], for row lengths the fused
+ * kernel takes (stof_toa_detect_fused_ok): Hilbert envelope -> gradient -> blur in LDS as in stof_toa_detect; the
+ * envelope goes to env_out[N, L] (required: the detection launch after the threshold, stof_grad_peak_detect, reads it)
+ * and the sum / sum of squares of the smoothed gradient are added to stats[0], stats[1] as stof_gradpeak_moments does.
+ * partials: device scratch of STOF_MOMENT_SLOTS * 16 doubles (zeroed here; the work-groups' sums are spread over that
+ * many cache lines and folded into stats at the end of the call, on the stream).                                      */
+#define STOF_MOMENT_SLOTS 64
+int stof_toa_moments(const float* frame, int64_t N, int64_t L, int32_t grad_step, const float* taps, int32_t radius,
+                     float* env_out, double* partials, double* stats, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Neighbours of the hot path (SURVEY.md section 8f "next rows").
  * ------------------------------------------------------------------------- */

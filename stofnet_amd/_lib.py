@@ -90,6 +90,8 @@ _SIGNATURES = {
     'stof_toa_detect': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32, _c.c_float,
                                    _c.c_int32, _c.c_int32, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
                                    _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'stof_toa_moments': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32, _c.c_void_p,
+                                    _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'stof_iq2rf': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_double, _c.c_double, _c.c_double,
                               _c.c_int32, _c.c_void_p]),
     'stof_toa_rmse': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float,

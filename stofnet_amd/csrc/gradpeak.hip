@@ -12,10 +12,12 @@
 // One host read per call at most (flags = {Q9, Kmax}); no host sync inside.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include "stof_common.h"
 #include "stof_hip_util.h"
 #include "fft_small.h"
 #include "pair_io.h"
+#include "ct_twiddles.h"
 #include "gradpeak_core.h"
 
 namespace stof {
@@ -32,17 +34,22 @@ constexpr int LDS_BYTES = 160 * 1024;
 // 20 us of a 40 us kernel queueing there; 256 groups of 16 waves do not)
 constexpr int ROWS_WAVES = 4, MOMENT_WAVES = 16;
 
+// Dynamic LDS: a gradient buffer of ring_stride floats per wave.  (Copying the wave's whole row into LDS first, every
+// 16-byte load in flight at once, was measured and dropped: [4096, 2000] 29.9 us against 26.9 us for streaming straight
+// from HBM with the next iteration's samples requested one iteration ahead -- the copy is a phase nothing overlaps.)
 template <bool MOMENTS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void gradpeak_rows_kernel(const float* __restrict__ env, long long N, Config cf,
                                                                         const float* __restrict__ taps,
                                                                         const float* __restrict__ th_dev,
                                                                         float* __restrict__ echoes, float* __restrict__ reduced,
                                                                         int* __restrict__ counts, int* __restrict__ flags,
-                                                                        double* __restrict__ stats, float* __restrict__ blurred) {
+                                                                        double* __restrict__ stats, float* __restrict__ blurred,
+                                                                        int ring_stride) {
     __shared__ __attribute__((aligned(16))) float tp[stof_gp::TAPS_LDS];
-    __shared__ float rings[WAVES][512];
     __shared__ double red[2][WAVES];
+    extern __shared__ __attribute__((aligned(16))) float rows_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* const ring = rows_lds + (size_t)wave * ring_stride;
     stof_gp::stage_taps(tp, taps, cf.radius, tid, blockDim.x);
     if (th_dev != nullptr) {                                   // default threshold computed on the device (Q7)
         cf.th_pos = *th_dev;
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(64 * WAVES) void gradpeak_rows_kernel(const float* 
         if (MOMENTS && blurred != nullptr) {                   // keep the smoothed gradient for stof_grad_peak_detect_blurred
             const int nw = stof_gp::word_count(cf.L, cf.radius);
             float* const b = blurred + row * (long long)nw * 64;
-            stof_gp::stream_words<1>(cf, tp, rings[wave], lane, [&](int u, float (&v)[1]) { v[0] = e[u]; }, 0, nw - 1, true,
+            stof_gp::stream_words<1>(cf, tp, ring, lane, [&](int u, float (&v)[1]) { v[0] = e[u]; }, 0, nw - 1, true,
                                      [&](int c, int, unsigned long long, unsigned long long, unsigned long long, float sm) {
                                          mom[0] += (double)sm;
                                          mom[1] += (double)sm * (double)sm;
@@ -66,9 +73,10 @@ __global__ __launch_bounds__(64 * WAVES) void gradpeak_rows_kernel(const float* 
                                      });
             continue;
         }
-        stof_gp::stream_rows<1, MOMENTS>(
-            cf, tp, rings[wave], lane, [&](int u, float (&v)[1]) { v[0] = e[u]; }, [&](int, int i) { return e[i]; }, out, st, mom);
-        if constexpr (!MOMENTS) {
+        if constexpr (MOMENTS) {
+            stof_gp::moments_row_blocks(cf, tp, ring, lane, stof_gp::EnvRow{e}, mom);
+        } else {
+            stof_gp::detect_row_blocks(cf, tp, ring, lane, stof_gp::EnvRow{e}, out[0], st[0]);
             stof_gp::finish_row(st[0], cf, row, out[0], reduced, counts, flags, lane, true);
             kmax = st[0].nout > kmax ? st[0].nout : kmax;
         }
@@ -333,26 +341,41 @@ struct FusedParams {
     float* reduced;        // [N][echo_max][3] or nullptr
     int* counts;           // [N]
     int* flags;            // {Q9, Kmax}
-    float* env_out;        // optional [N][L]: also store the envelope (debug / callers that want it)
+    float* env_out;        // optional [N][L]: also store the envelope (the moments pass keeps it for the detection launch)
+    double* partials;      // MOMENTS: [STOF_MOMENT_SLOTS][16] doubles; a work-group adds {sum, sum of squares} of its smoothed
+                           // gradients to slot blockIdx & (SLOTS - 1), entries 0 and 1 (one 128-byte line per slot)
     long long N;
     Config cf;
     stof_fft::Plan plan;
 };
 
+#ifdef STOF_GP_STAMPS                                              // diagnostic build: cycles per phase of waves 0 and 1 of each group
+constexpr int GP_STAMP_SLOTS = 8192;
+__device__ unsigned long long g_gp_stamps[GP_STAMP_SLOTS][8];
+#define GP_STAMP(i) do { if (lane == 0 && wave < 2) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         g_gp_stamps[(2 * blockIdx.x + wave) % GP_STAMP_SLOTS][i] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define GP_STAMP(i) do { } while (0)
+#endif
+
 // One work-group (T = 64, 128 or 256 threads) per pair of waveforms; after the transform wave r of the group streams
-// row r of the pair (a single-wave group takes both rows one after the other).
+// row r of the pair (a single-wave group takes both rows one after the other).  MOMENTS: the pre-pass of the default
+// threshold (Q7) -- the streaming stage sums the smoothed gradient instead of detecting.
+template <bool MOMENTS>
 __global__ __launch_bounds__(256, 4) void toa_fused_kernel(const FusedParams p) {
     using namespace stof_fft;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int n = p.cf.L, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
-    const int RG = stof_gp::ring_entries(p.cf.radius);
-    // LDS: pair image [n] | twiddle tables | tap image | two gradient rings
+    // LDS: pair image [n] | twiddle tables | tap image | two gradient buffers
     cf* const Z = reinterpret_cast<cf*>(lds);
     cf* const ta = Z + n;
     cf* const tb = ta + TW_A;
     const int nb = (n + TW_A - 1) / TW_A;
     float* const tp = reinterpret_cast<float*>(tb + nb + (nb & 1));              // 16-byte aligned (tables are 8-byte entries)
     float* const rings = tp + stof_gp::TAPS_LDS;
+#ifdef STOF_GP_STAMPS
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
     stof_gp::stage_taps(tp, p.taps, p.cf.radius, tid, T);
     for (int t = tid; t < TW_A + nb; t += T) {
         const double k = t < TW_A ? (double)t : (double)(t - TW_A) * (double)TW_A;
@@ -362,15 +385,19 @@ __global__ __launch_bounds__(256, 4) void toa_fused_kernel(const FusedParams p) 
     }
     const Twiddles tw{ta, tb};
     const long long npairs = (p.N + 1) / 2;
+    double mom[2] = {0.0, 0.0};
     for (long long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const long long row = 2 * pr;
         const float* xr = p.x + row * (size_t)n;
         const bool second = row + 1 < p.N;
         const float* const x2 = second ? xr + n : nullptr;
         __syncthreads();                                          // tables built / previous pair fully consumed
+        GP_STAMP(5);
         stof_io::load_pair<4>(Z, xr, x2, n, tid, T);
         __syncthreads();
+        GP_STAMP(0);
         analytic_in_place(Z, p.plan, tw, tid, T, [] { __syncthreads(); });
+        GP_STAMP(1);
         float* const eo = p.env_out ? p.env_out + row * (size_t)n : nullptr;
         stof_io::unmix_pair<4>(                                   // analytic signals -> the two envelopes, in place
             Z, xr, x2, n, tid, T,
@@ -392,20 +419,228 @@ __global__ __launch_bounds__(256, 4) void toa_fused_kernel(const FusedParams p) 
                 if (eo) { eo[i] = e.x; if (second) eo[n + i] = e.y; }
             });
         __syncthreads();
+        GP_STAMP(2);
         const float* const E = reinterpret_cast<const float*>(Z);            // E[2 u + r] = envelope of row r at sample u
 #ifdef STOF_GP_SKIP                                              // diagnostic build: transform + envelope only
         continue;
 #endif
         for (int r = wave; r < (second ? 2 : 1); r += nwaves) {
             if (r >= 2) break;
-            float* const out[1] = {p.echoes + (row + r) * p.cf.cap * 3};
-            RowState st[1];
-            double mom[2] = {0.0, 0.0};
-            stof_gp::stream_rows<1, false>(
-                p.cf, tp, rings + (size_t)(wave & 1) * 2 * RG, lane, [&](int u, float (&v)[1]) { v[0] = E[2 * u + r]; },
-                [&](int, int i) { return E[2 * i + r]; }, out, st, mom);
-            stof_gp::finish_row(st[0], p.cf, row + r, out[0], p.reduced, p.counts, p.flags, lane);
+            float* const ring = rings + (size_t)(wave & 1) * stof_gp::block_buf_floats(p.cf.radius);
+            const stof_gp::EnvPairLds env{E + r};
+            if constexpr (MOMENTS) {
+                stof_gp::moments_row_blocks(p.cf, tp, ring, lane, env, mom);
+            } else {
+                float* const out = p.echoes + (row + r) * p.cf.cap * 3;
+                RowState st;
+                stof_gp::detect_row_blocks(p.cf, tp, ring, lane, env, out, st);
+                GP_STAMP(3);
+                stof_gp::finish_row(st, p.cf, row + r, out, p.reduced, p.counts, p.flags, lane);
+                GP_STAMP(4);
+            }
         }
+    }
+    if constexpr (MOMENTS) {
+        // one pair of double atomics per work-group: ~90 per microsecond go through on ONE address (2048 groups would
+        // queue for 45 us), so the sums are spread over STOF_MOMENT_SLOTS cache lines and folded by stof_gradpeak_fold
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mom[0] += __shfl_xor(mom[0], o);
+            mom[1] += __shfl_xor(mom[1], o);
+        }
+        __syncthreads();                                          // the gradient buffers are free
+        double* const red = reinterpret_cast<double*>(tp);       // (the tap image is 16-byte aligned and no longer needed)
+        if (lane == 0) { red[wave] = mom[0]; red[4 + wave] = mom[1]; }
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < nwaves; ++w) { a += red[w]; b += red[4 + w]; }
+            double* const slot = p.partials + 16 * (blockIdx.x & (STOF_MOMENT_SLOTS - 1));
+            atomicAdd(&slot[0], a);
+            atomicAdd(&slot[1], b);
+        }
+    }
+}
+
+// stats[0..1] += the slots of a moments launch (one wave; slot s = entries 16 s, 16 s + 1)
+__global__ void gradpeak_fold_kernel(const double* __restrict__ partials, double* __restrict__ stats) {
+    const int lane = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int s = lane; s < STOF_MOMENT_SLOTS; s += 64) { a += partials[16 * s]; b += partials[16 * s + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (lane == 0) { stats[0] += a; stats[1] += b; }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// toa_detect fused, compile-time FFT plan (row lengths 1536 / 2000 / 2048): the transform of hilbert_ct_kernel
+// (fft_small.h analytic_ct: twiddles from a constant table, padded conflict-free slot, rows in registers from the load to
+// the un-mixing) in front of the block streamer.  A work-group holds PPW pairs, WPP waves per pair; after the transform
+// the envelopes are written back into the slot as a linear interleaved image E[2 u + r] (below the padded positions
+// still to be read: position(4 q) <= padded position(4 q)), and wave w of the pair streams row w (WPP = 1: both rows).
+// ----------------------------------------------------------------------------------------------------------------
+template <int N, int WPP, int PPW, bool MOMENTS>
+__global__ __launch_bounds__(64 * WPP * PPW) void toa_fused_ct_kernel(const FusedParams p) {
+    using namespace stof_fft;
+    static_assert(WPP == 1 || WPP == 2, "one streaming wave per row at most");
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    constexpr int T = 64 * WPP, TT = T * PPW, IO = (N / 4 + T - 1) / T;
+    constexpr int TWP = stof_ct::twiddle_lds_entries<N>(), SLOT = ct_slot_entries(N);
+    cf* const W = reinterpret_cast<cf*>(lds);
+    const int slot = threadIdx.x / T, tid = threadIdx.x % T, lane = tid & 63, wv = tid >> 6;
+    cf* const Z = W + TWP + slot * SLOT;
+    float* const tp = reinterpret_cast<float*>(W + TWP + PPW * SLOT);            // (TWP and SLOT are even: 16-byte aligned)
+    float* const ring = tp + stof_gp::TAPS_LDS + (size_t)(slot * WPP + wv) * stof_gp::block_buf_floats(p.cf.radius);
+    const long long npairs = (p.N + 1) / 2, stride = (long long)gridDim.x * PPW;
+    long long pr = (long long)blockIdx.x * PPW + slot;
+    // (the rows are not kept in registers across the transform as hilbert_ct_kernel does: the streaming stage wants
+    // four waves per SIMD, i.e. 128 registers; the un-mixing reads them again -- from L2)
+    stof_ct::stage_twiddles<N>(lds, threadIdx.x, TT);
+    stof_gp::stage_taps(tp, p.taps, p.cf.radius, threadIdx.x, TT);
+    __syncthreads();
+    double mom[2] = {0.0, 0.0};
+    for (long long p0 = (long long)blockIdx.x * PPW; p0 < npairs; p0 += stride, pr += stride) {
+        const bool active = pr < npairs;
+        if (WPP == 1 && !active) break;                          // a lone wave: nobody waits for it
+        auto sync = [] { if (WPP > 1) __syncthreads(); else wave_lds_sync(); };
+        sync();                                                   // previous pair fully streamed
+        const float* const xr = p.x + 2 * pr * (size_t)N;
+        const float* const x2 = (active && 2 * pr + 1 < p.N) ? xr + N : nullptr;
+        if (active) {
+            stof_io::PairRegs<IO> cur;
+            stof_io::load_pair_regs(cur, xr, x2, N, tid, T);
+            stof_io::stage_pair<IO, true>(Z, cur, N, tid, T);
+        }
+        sync();
+        analytic_ct<N, T, CtOpt<true, false>>(Z, W, tid, sync);  // idle slots of a multi-wave group keep the barrier count
+        const long long row = 2 * pr;
+        const bool second = active && row + 1 < p.N;
+        float* const eo = (active && p.env_out) ? p.env_out + row * (size_t)N : nullptr;
+        constexpr int nq = N >> 2;
+        // analytic signals (padded slot) -> the two envelopes, linear and interleaved, in place.  One wave per pair runs
+        // in lockstep, so a piece's reads precede its writes by program order; two waves read everything first.
+        auto rows_at = [&](int q, float4& xa4, float4& xb4) {
+            xa4 = *reinterpret_cast<const stof_io::f4a*>(xr + 4 * q);
+            xb4 = x2 ? *reinterpret_cast<const stof_io::f4a*>(x2 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        auto emit = [&](int q, const float4& z0, const float4& z1, const float4& xa4, const float4& xb4) {
+            const float xa[4] = {xa4.x, xa4.y, xa4.z, xa4.w}, xb[4] = {xb4.x, xb4.y, xb4.z, xb4.w};
+            const float re[4] = {z0.x, z0.z, z1.x, z1.z}, im[4] = {z0.y, z0.w, z1.y, z1.w};
+            float ea[4], eb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                          // v1 = Im Z - x2, v2 = x1 - Re Z (pair_io.h)
+                ea[e] = stof_io::envelope(xa[e], im[e] - xb[e]);
+                eb[e] = stof_io::envelope(xb[e], xa[e] - re[e]);
+            }
+            stof_io::f4a* d = reinterpret_cast<stof_io::f4a*>(Z + 4 * q);
+            d[0] = make_float4(ea[0], eb[0], ea[1], eb[1]);
+            d[1] = make_float4(ea[2], eb[2], ea[3], eb[3]);
+            if (eo) {
+                *reinterpret_cast<float4*>(eo + 4 * q) = make_float4(ea[0], ea[1], ea[2], ea[3]);
+                if (second) *reinterpret_cast<float4*>(eo + N + 4 * q) = make_float4(eb[0], eb[1], eb[2], eb[3]);
+            }
+        };
+        if constexpr (WPP == 1) {
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < IO; ++k) {
+                    const int q = tid + k * T;
+                    if (q < nq) {
+                        const stof_io::f4a* sp = reinterpret_cast<const stof_io::f4a*>(Z + 4 * q + 2 * (q >> 2));
+                        const float4 z0 = sp[0], z1 = sp[1];
+                        float4 xa4, xb4;
+                        rows_at(q, xa4, xb4);
+                        wave_lds_sync();
+                        emit(q, z0, z1, xa4, xb4);
+                        wave_lds_sync();
+                    }
+                }
+            }
+            wave_lds_sync();
+        } else {
+            float4 z0[IO], z1[IO], xa4[IO], xb4[IO];
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < IO; ++k) {
+                    const int q = tid + k * T;
+                    if (q < nq) {
+                        const stof_io::f4a* sp = reinterpret_cast<const stof_io::f4a*>(Z + 4 * q + 2 * (q >> 2));
+                        z0[k] = sp[0]; z1[k] = sp[1];
+                        rows_at(q, xa4[k], xb4[k]);
+                    }
+                }
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < IO; ++k) {
+                    const int q = tid + k * T;
+                    if (q < nq) emit(q, z0[k], z1[k], xa4[k], xb4[k]);
+                }
+            }
+            __syncthreads();
+        }
+        if (!active) continue;
+        const float* const E = reinterpret_cast<const float*>(Z);  // E[2 u + r] = envelope of row r at sample u
+        for (int r = wv; r < (second ? 2 : 1); r += WPP) {
+            const stof_gp::EnvPairLds env{E + r};
+            if constexpr (MOMENTS) {
+                stof_gp::moments_row_blocks(p.cf, tp, ring, lane, env, mom);
+            } else {
+                float* const out = p.echoes + (row + r) * p.cf.cap * 3;
+                RowState st;
+                stof_gp::detect_row_blocks(p.cf, tp, ring, lane, env, out, st);
+                stof_gp::finish_row(st, p.cf, row + r, out, p.reduced, p.counts, p.flags, lane);
+            }
+        }
+    }
+    if constexpr (MOMENTS) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mom[0] += __shfl_xor(mom[0], o);
+            mom[1] += __shfl_xor(mom[1], o);
+        }
+        __syncthreads();                                          // (every thread leaves the loop: WPP = 1 waves break, others run it out)
+        double* const red = reinterpret_cast<double*>(tp);       // the tap image is no longer needed
+        const int w = threadIdx.x >> 6;
+        if (lane == 0) { red[w] = mom[0]; red[8 + w] = mom[1]; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0, b = 0.0;
+            for (int i = 0; i < WPP * PPW; ++i) { a += red[i]; b += red[8 + i]; }
+            double* const sl = p.partials + 16 * (blockIdx.x & (STOF_MOMENT_SLOTS - 1));
+            atomicAdd(&sl[0], a);
+            atomicAdd(&sl[1], b);
+        }
+    }
+}
+
+template <int N, int WPP, int PPW, bool MOMENTS>
+int launch_fused_ct(const FusedParams& p, int64_t rows, int radius, hipStream_t stream) {
+    const size_t lds = ((size_t)stof_ct::twiddle_lds_entries<N>() + (size_t)PPW * stof_fft::ct_slot_entries(N)) * sizeof(float2) +
+                       ((size_t)stof_gp::TAPS_LDS + (size_t)PPW * WPP * stof_gp::block_buf_floats(radius)) * sizeof(float);
+    if (lds > (size_t)LDS_BYTES) return STOF_ERR_UNSUPPORTED;
+    static stof::LdsLimitOnce once;
+    if (int st = once.ensure(reinterpret_cast<const void*>(&toa_fused_ct_kernel<N, WPP, PPW, MOMENTS>), LDS_BYTES)) return st;
+    const int64_t npairs = (rows + 1) / 2, groups = (npairs + PPW - 1) / PPW;
+    int64_t grid = (int64_t)stof::device_cu_count() * (int64_t)((size_t)LDS_BYTES / lds);
+    if (grid > groups) grid = groups;
+    hipLaunchKernelGGL((toa_fused_ct_kernel<N, WPP, PPW, MOMENTS>), dim3((unsigned)grid), dim3(64 * WPP * PPW), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+// row lengths with a compile-time plan; -1: none (or STOF_FUSED_CT=0, or rows that are not 16-byte aligned).  Two waves per
+// pair, two pairs per work-group: one wave per pair and four pairs (hilbert_ct_kernel's shape for these lengths) leaves a
+// single wave to stream both rows, 80 us on [4096, 2000] against 58.
+template <bool MOMENTS>
+int try_launch_fused_ct(const FusedParams& p, int64_t rows, int64_t L, int radius, hipStream_t stream) {
+    static const int mode = [] { const char* e = getenv("STOF_FUSED_CT"); return e ? atoi(e) : 1; }();   // 0: run-time plan kernel (A/B)
+    if (mode == 0 || (reinterpret_cast<size_t>(p.x) & 15) || (p.env_out && (reinterpret_cast<size_t>(p.env_out) & 15))) return -1;
+    switch (L) {
+        case 1536: return launch_fused_ct<1536, 2, 2, MOMENTS>(p, rows, radius, stream);
+        case 2000: return launch_fused_ct<2000, 2, 2, MOMENTS>(p, rows, radius, stream);
+        case 2048: return launch_fused_ct<2048, 2, 2, MOMENTS>(p, rows, radius, stream);
+        default: return -1;
     }
 }
 
@@ -418,7 +653,7 @@ size_t fused_lds_bytes(int64_t n, int radius, stof_fft::Plan* plan) {
     static const int64_t max_l = [] { const char* e = getenv("STOF_FUSED_MAX_L"); return e ? (int64_t)atoll(e) : (int64_t)FUSED_MAX_L; }();
     if (n > max_l || !stof::hilbert_fast_lds_bytes(n, plan)) return 0;
     return ((size_t)n + stof_fft::twiddle_entries((int)n) + 1) * sizeof(float2) +
-           ((size_t)stof_gp::TAPS_LDS + 2 * stof_gp::ring_floats(radius)) * sizeof(float);
+           ((size_t)stof_gp::TAPS_LDS + 2 * stof_gp::block_buf_floats(radius)) * sizeof(float);
 }
 
 bool bad_common(int64_t N, int64_t L, int32_t grad_step, int32_t radius, int64_t cap) {
@@ -437,6 +672,21 @@ Config make_config(int64_t L, int32_t grad_step, int32_t radius, float threshold
     return cf;
 }
 
+// launch of gradpeak_rows_kernel with its gradient buffers
+template <bool MOMENTS, int WAVES>
+int launch_rows(const float* env, int64_t N, const Config& cf, const float* taps, const float* th_dev, float* echoes, float* reduced,
+                int* counts, int* flags, double* stats, float* blurred, int64_t groups_per_cu, hipStream_t stream) {
+    int ring_stride = stof_gp::block_buf_floats(cf.radius);
+    if (blurred && stof_gp::ring_floats(cf.radius) > ring_stride) ring_stride = stof_gp::ring_floats(cf.radius);   // stream_words' ring
+    const size_t dyn = (size_t)WAVES * ring_stride * sizeof(float);
+    int64_t grid = (N + WAVES - 1) / WAVES;
+    const int64_t maxg = (int64_t)stof::device_cu_count() * groups_per_cu;
+    if (grid > maxg) grid = maxg;
+    hipLaunchKernelGGL((gradpeak_rows_kernel<MOMENTS, WAVES>), dim3((unsigned)grid), dim3(64 * WAVES), dyn, stream, env, (long long)N, cf,
+                       taps, th_dev, echoes, reduced, counts, flags, stats, blurred, ring_stride);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
 }  // namespace
 
 extern "C" int stof_gradpeak_moments(const float* env, int64_t N, int64_t L, int32_t grad_step, const float* taps,
@@ -450,13 +700,8 @@ extern "C" int stof_gradpeak_moments(const float* env, int64_t N, int64_t L, int
         if (launch_split<true>(env, N, cf, taps, nullptr, nullptr, nullptr, nullptr, nullptr, stats, static_cast<hipStream_t>(stream), &st))
             return st;
     }
-    int64_t grid = (N + MOMENT_WAVES - 1) / MOMENT_WAVES;
-    const int64_t maxg = (int64_t)stof::device_cu_count() * 2;
-    if (grid > maxg) grid = maxg;
-    hipLaunchKernelGGL((gradpeak_rows_kernel<true, MOMENT_WAVES>), dim3((unsigned)grid), dim3(64 * MOMENT_WAVES), 0,
-                       static_cast<hipStream_t>(stream), env, (long long)N, cf, taps, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       stats, (float*)nullptr);
-    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+    return launch_rows<true, MOMENT_WAVES>(env, N, cf, taps, nullptr, nullptr, nullptr, nullptr, nullptr, stats, nullptr, 2,
+                                           static_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t stof_gradpeak_blurred_stride(int64_t L, int32_t radius) {
@@ -469,13 +714,8 @@ extern "C" int stof_gradpeak_moments_store(const float* env, int64_t N, int64_t 
     if (N == 0 || L == 0) return STOF_OK;
     if (radius > stof_gp::MAXRAD || L > 0x3fffffffLL) return STOF_ERR_UNSUPPORTED;
     const Config cf = make_config(L, grad_step, radius, 0.f, 0, 0, 0, 0);
-    int64_t grid = (N + MOMENT_WAVES - 1) / MOMENT_WAVES;
-    const int64_t maxg = (int64_t)stof::device_cu_count() * 2;
-    if (grid > maxg) grid = maxg;
-    hipLaunchKernelGGL((gradpeak_rows_kernel<true, MOMENT_WAVES>), dim3((unsigned)grid), dim3(64 * MOMENT_WAVES), 0,
-                       static_cast<hipStream_t>(stream), env, (long long)N, cf, taps, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       stats, blurred);
-    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+    return launch_rows<true, MOMENT_WAVES>(env, N, cf, taps, nullptr, nullptr, nullptr, nullptr, nullptr, stats, blurred, 2,
+                                           static_cast<hipStream_t>(stream));
 }
 
 extern "C" int stof_gradpeak_threshold(const double* stats, float* threshold_out, void* stream) {
@@ -501,13 +741,8 @@ extern "C" int stof_grad_peak_detect(const float* env, int64_t N, int64_t L, int
         if (launch_split<false>(env, N, cf, taps, threshold_dev, echoes, reduced, counts, flags, nullptr, static_cast<hipStream_t>(stream), &st))
             return st;
     }
-    int64_t grid = (N + ROWS_WAVES - 1) / ROWS_WAVES;
-    const int64_t maxg = (int64_t)stof::device_cu_count() * 8;
-    if (grid > maxg) grid = maxg;
-    hipLaunchKernelGGL((gradpeak_rows_kernel<false, ROWS_WAVES>), dim3((unsigned)grid), dim3(64 * ROWS_WAVES), 0,
-                       static_cast<hipStream_t>(stream), env, (long long)N, cf, taps, threshold_dev, echoes, reduced, counts, flags,
-                       nullptr, (float*)nullptr);
-    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+    return launch_rows<false, ROWS_WAVES>(env, N, cf, taps, threshold_dev, echoes, reduced, counts, flags, nullptr, nullptr, 8,
+                                          static_cast<hipStream_t>(stream));
 }
 
 extern "C" int stof_grad_peak_detect_blurred(const float* env, const float* blurred, int64_t N, int64_t L, int32_t radius,
@@ -533,6 +768,33 @@ extern "C" int stof_toa_detect_fused_ok(int64_t L, int32_t radius) {
     return fused_lds_bytes(L, radius, nullptr) != 0 && radius <= stof_gp::MAXRAD;
 }
 
+namespace {
+
+// shared launch of the fused kernel (detection or moments pre-pass)
+template <bool MOMENTS>
+int launch_fused(FusedParams& p, int64_t N, int64_t L, int32_t radius, hipStream_t stream) {
+    {
+        const int st = try_launch_fused_ct<MOMENTS>(p, N, L, radius, stream);
+        if (st != -1 && st != STOF_ERR_UNSUPPORTED) return st;
+    }
+    const size_t lds = fused_lds_bytes(L, radius, &p.plan);
+    if (!lds) return STOF_ERR_UNSUPPORTED;            // caller falls back to stof_hilbert + stof_grad_peak_detect
+    static stof::LdsLimitOnce once;
+    if (int st = once.ensure(reinterpret_cast<const void*>(&toa_fused_kernel<MOMENTS>), LDS_BYTES)) return st;
+    const int64_t npairs = (N + 1) / 2;
+    int64_t per_cu = (int64_t)LDS_BYTES / (int64_t)lds;
+    if (per_cu > 16) per_cu = 16;
+    int threads = 64;                                              // 16 waves per CU whatever the row length
+    while (threads < 256 && per_cu * (threads / 64) < 16) threads *= 2;
+    if (const char* e = getenv("STOF_FUSED_THREADS")) threads = atoi(e);       // tuning / A-B switch
+    int64_t grid = (int64_t)stof::device_cu_count() * per_cu;
+    if (grid > npairs) grid = npairs;
+    hipLaunchKernelGGL(toa_fused_kernel<MOMENTS>, dim3((unsigned)grid), dim3(threads), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+}  // namespace
+
 extern "C" int stof_toa_detect(const float* frame, int64_t N, int64_t L, int32_t grad_step, const float* taps, int32_t radius,
                                float threshold, int32_t ival_min, int32_t ival_max, int64_t echo_max, float* echoes,
                                int64_t cap, float* reduced, int32_t* counts, int32_t* flags, float* env_out, void* stream) {
@@ -542,23 +804,38 @@ extern "C" int stof_toa_detect(const float* frame, int64_t N, int64_t L, int32_t
     if (echo_max > 0 && cap > 4096) return STOF_ERR_UNSUPPORTED;      // reduce_row selects among <= 64 x 64 entries per row
     if (N == 0) return STOF_OK;
     if (N > 0x7fffffffLL || radius > stof_gp::MAXRAD) return STOF_ERR_UNSUPPORTED;
+    if (!fused_lds_bytes(L, radius, nullptr)) return STOF_ERR_UNSUPPORTED;
     FusedParams p;
-    const size_t lds = fused_lds_bytes(L, radius, &p.plan);
-    if (!lds) return STOF_ERR_UNSUPPORTED;            // caller falls back to stof_hilbert + stof_grad_peak_detect
-    static stof::LdsLimitOnce once;
-    if (int st = once.ensure(reinterpret_cast<const void*>(&toa_fused_kernel), LDS_BYTES)) return st;
     p.x = frame; p.taps = taps; p.echoes = echoes; p.reduced = echo_max > 0 ? reduced : nullptr;
-    p.counts = counts; p.flags = flags; p.env_out = env_out; p.N = N;
+    p.counts = counts; p.flags = flags; p.env_out = env_out; p.partials = nullptr; p.N = N;
     p.cf = make_config(L, grad_step, radius, threshold, ival_min, ival_max, cap, echo_max);
     if (hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return STOF_ERR_HIP;
-    const int64_t npairs = (N + 1) / 2;
-    int64_t per_cu = (int64_t)LDS_BYTES / (int64_t)lds;
-    if (per_cu > 16) per_cu = 16;
-    int threads = 64;                                              // 16 waves per CU whatever the row length
-    while (threads < 256 && per_cu * (threads / 64) < 16) threads *= 2;
-    if (const char* e = getenv("STOF_FUSED_THREADS")) threads = atoi(e);       // tuning / A-B switch
-    int64_t grid = (int64_t)stof::device_cu_count() * per_cu;
-    if (grid > npairs) grid = npairs;
-    hipLaunchKernelGGL(toa_fused_kernel, dim3((unsigned)grid), dim3(threads), lds, static_cast<hipStream_t>(stream), p);
+    return launch_fused<false>(p, N, L, radius, static_cast<hipStream_t>(stream));
+}
+
+#ifdef STOF_GP_STAMPS
+extern "C" int stof_debug_gp_stamps(unsigned long long* out, int reset) {      // out[8]: sums over the slots
+    static unsigned long long host[GP_STAMP_SLOTS][8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gp_stamps), sizeof(host)) != hipSuccess) return STOF_ERR_HIP;
+    for (int i = 0; i < 8; ++i) { out[i] = 0; for (int sl = 0; sl < GP_STAMP_SLOTS; ++sl) out[i] += host[sl][i]; }
+    if (reset) { memset(host, 0, sizeof(host)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_gp_stamps), host, sizeof(host)) != hipSuccess) return STOF_ERR_HIP; }
+    return STOF_OK;
+}
+#endif
+
+extern "C" int stof_toa_moments(const float* frame, int64_t N, int64_t L, int32_t grad_step, const float* taps, int32_t radius,
+                                float* env_out, double* partials, double* stats, void* stream) {
+    if (!frame || !taps || !env_out || !partials || !stats || bad_common(N, L, grad_step, radius, 0)) return STOF_ERR_BAD_ARG;
+    if (N == 0 || L == 0) return STOF_OK;
+    if (N > 0x7fffffffLL || radius > stof_gp::MAXRAD) return STOF_ERR_UNSUPPORTED;
+    if (!fused_lds_bytes(L, radius, nullptr)) return STOF_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(partials, 0, (size_t)STOF_MOMENT_SLOTS * 16 * sizeof(double), s) != hipSuccess) return STOF_ERR_HIP;
+    FusedParams p;
+    p.x = frame; p.taps = taps; p.echoes = nullptr; p.reduced = nullptr; p.counts = nullptr; p.flags = nullptr;
+    p.env_out = env_out; p.partials = partials; p.N = N;
+    p.cf = make_config(L, grad_step, radius, 0.f, 0, 0, 0, 0);
+    if (int st = launch_fused<true>(p, N, L, radius, s)) return st;
+    hipLaunchKernelGGL(gradpeak_fold_kernel, dim3(1), dim3(64), 0, s, partials, stats);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }

@@ -15,6 +15,7 @@
 // one iteration later (an edge at the last lane needs the first flag of the next word).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "fft_small.h"      // wave_lds_sync
 
 namespace stof_gp {
@@ -262,22 +263,195 @@ __device__ __forceinline__ void stream_rows(const Config& cf, const float* __res
                      });
 }
 
-// Pairing of a row from its stored flag words F[3 c + {0, 1, 2}] = (P, M, V) of iteration c, c = 0 .. nwords - 1 (LDS, by
-// one wave).  64 iterations at a time: lane l forms the edge words of iteration c0 + l in vector registers, a ballot
-// tells which iterations hold an onset, and the scalar loop visits only those and the stretch behind a pending onset.
-template <class EnvAt>
-__device__ __forceinline__ void pair_stored_words(RowState& st, const unsigned long long* __restrict__ F, int nwords, int lane,
-                                                  const Config& cf, float* __restrict__ out, EnvAt env_at) {
-    const int rad = cf.radius;
-    for (int c0 = 1; c0 < nwords; c0 += 64) {
-        const int c = c0 + lane;
-        unsigned long long EP = 0, EM = 0;
-        if (c < nwords) {
-            const unsigned long long Pp = F[3 * (c - 1)], Mp = F[3 * (c - 1) + 1], Vp = F[3 * (c - 1) + 2];
-            const unsigned long long P = F[3 * c], M = F[3 * c + 1];
-            EP = ~Pp & ((Pp >> 1) | (P << 63)) & Vp;
-            EM = ~Mp & ((Mp >> 1) | (M << 63)) & Vp;
+// ----------------------------------------------------------------------------------------------------------------
+// Block streamer (r3).  stream_words above is one dependent chain per 64 samples -- envelope reads -> division -> ring
+// -> 2 rad + 1 fmaf -> ballots -> scalar pairing -- and a wave waits out each link: measured ~2,500 cycles per word and
+// wave with 4 waves per SIMD, where its ~135 instructions need ~600.  Here an iteration takes WPI words at once
+// (independent chains the hardware overlaps), the division by the wave's constant 2 g is a multiply and two FMAs, and the
+// pairing leaves the loop: the flag words of up to 64 iterations collect in vector registers (FlagBatch) and are paired
+// together (pair_batch below).
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int WPI = 4;                           // words of 64 samples per iteration
+// Gradient buffer of a wave (LDS): the last `hist` gradients of the previous iteration, then the 64 WPI new ones -- a
+// linear image, so every blur read is `base + immediate` with no wrap arithmetic and every gradient is stored once.
+__host__ __device__ constexpr int block_hist(int rad) { return rad <= 32 ? 64 : 192; }             // >= 2 rad, whole words
+// (+ 8 zeros: the taps are read eight at a time, and the zero taps past 2 rad + 1 must meet finite values)
+__host__ __device__ constexpr int block_buf_floats(int rad) { return block_hist(rad) + 64 * WPI + 8; }
+__host__ __device__ constexpr int block_iterations(int L, int rad) { return (word_count(L, rad) + WPI - 1) / WPI; }
+
+// RN(x / den) for den = 2 g with rcp = RN(1 / den): q = RN(x rcp) is within an ulp of the quotient, r = x - q den is exact
+// in an FMA, and RN(q + r rcp) is the correctly rounded quotient (Markstein's final division step; it needs rcp correctly
+// rounded -- a true division -- and no underflow in r).  Safe for |x| in [2^-63, 2^63) and for x == 0; the caller falls
+// back to the true division for an iteration that holds anything else (div_unsafe_any).
+__device__ __forceinline__ float div_by_const(float x, float den, float rcp) {
+    const float q = x * rcp;
+    const float r = __builtin_fmaf(-q, den, x);
+    return __builtin_fmaf(r, rcp, q);
+}
+// |x| as ordered integers: largest of the four, and smallest with 0 mapped to the top (a - 1 wraps)
+__device__ __forceinline__ bool div_unsafe_any(const float (&x)[4]) {
+    unsigned a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = __float_as_uint(x[k]) << 1;            // drops the sign: 2 |x| bits
+    const unsigned hi = max(max(a[0], a[1]), max(a[2], a[3]));
+    const unsigned lo = min(min(a[0] - 1u, a[1] - 1u), min(a[2] - 1u, a[3] - 1u));
+    return hi >= (0x5f000000u << 1) || lo < (0x20000000u << 1) - 1u;           // 2^63 and 2^-63
+}
+
+// Envelope accessors of the block streamer:
+//   at(i)    : envelope[i], 0 <= i < L
+//   ptr(i)   : address of envelope[i]; consecutive samples are STRIDE floats apart (the inner iterations read
+//              ptr(u)[STRIDE * constant], which becomes an immediate offset of the load)
+struct EnvRow {                                  // a row in global memory
+    const float* e;
+    static constexpr int STRIDE = 1;
+    __device__ __forceinline__ float at(int i) const { return e[i]; }
+    __device__ __forceinline__ const float* ptr(int i) const { return e + i; }
+};
+struct EnvPairLds {                              // row r of a pair interleaved in LDS: E[2 u + r]
+    const float* e;                              // = E + r
+    static constexpr int STRIDE = 2;
+    __device__ __forceinline__ float at(int i) const { return e[2 * i]; }
+    __device__ __forceinline__ const float* ptr(int i) const { return e + 2 * i; }
+};
+
+//   env                    : EnvRow / EnvPairLds
+//   ring                   : LDS, block_buf_floats(rad) floats owned by this wave
+//   sink(c, P, M, sm)      : iteration c = words c .. c + WPI - 1 (c a multiple of WPI): P[k], M[k] the flag words of word
+//                            c + k (bit l <=> sample 64 (c + k) + l - rad; zero outside the row), sm[k] this lane's
+//                            blurred gradient there (0 outside the row).  Words >= word_count(L, rad) are all zero.
+//   batch_end(next)        : after every iteration, next = c + WPI
+// The kernels are bound by the number of vector instructions they issue (4 waves per SIMD, every lane busy), so an
+// iteration whose 256 samples lie inside the row -- all but the first and the last one or two -- runs a form without
+// index clamps, end-of-row masks and one-sided differences (wave-uniform choice).
+template <class Env, class Sink, class BatchEnd>
+__device__ __forceinline__ void stream_blocks(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring, int lane,
+                                              const Env env, Sink sink, BatchEnd batch_end) {
+    static_assert(WPI == 4, "div_unsafe_any and the history writes assume four words per iteration");
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The clamped sample indices of the first and last iterations depend on the lane and the row length only; left to
+    // itself the compiler computes them once per kernel and parks ~50 registers on them across the row loop (one wave
+    // per SIMD less).  An opaque copy of the lane ties them to this call.
+    asm volatile("" : "+v"(lane));
+#endif
+    const int L = cf.L, rad = cf.radius, niter = block_iterations(L, rad);
+    const float sp = cf.spacing, two_sp = 2.0f * cf.spacing, rcp2 = 1.0f / two_sp;
+    const int H = block_hist(rad), ntaps = 2 * rad + 1;
+    for (int q = lane; q < H + 64 * WPI + 8; q += 64) ring[q] = 0.f;  // = the blur's zero padding left of the row
+    // Iteration `it` covers the samples u = 256 it .. 256 it + 255 (gradients) and i = u - rad (blurred values, flags).
+    // Iterations 1 .. n_in have every u in 1 .. L - 2 (central differences, no clamps) and every i in 0 .. L - 1.
+    const int n_in = L >= 513 ? (L - 257) / 256 : 0;
+    float ea[WPI], eb[WPI];
+    float g[WPI] = {0.f, 0.f, 0.f, 0.f};
+    const float* const r0 = ring + (H - 2 * rad + lane);
+    // one iteration; INNER: `it` is in 1 .. n_in, NEXT_INNER: so is it + 1 (the envelope samples of the next iteration
+    // are requested while this one is blurred)
+    auto iteration = [&](const int it, auto inner_tag, auto next_inner_tag) {
+        constexpr bool INNER = decltype(inner_tag)::value, NEXT_INNER = decltype(next_inner_tag)::value;
+        const int c = WPI * it;
+        // the newest H gradients (previous iteration, still in registers) become the history of this one; wave_lds_sync()
+        // orders these stores behind the previous iteration's reads for the compiler -- the buffer is shared by the lanes
+        // of this wave only, and the hardware executes a wave's LDS instructions in order
+        stof_fft::wave_lds_sync();
+        if (H == 64) ring[lane] = g[3];
+        else { ring[lane] = g[1]; ring[64 + lane] = g[2]; ring[128 + lane] = g[3]; }
+#pragma unroll
+        for (int k = 0; k < WPI; ++k) g[k] = ea[k] - eb[k];
+        if (INNER && !__ballot(div_unsafe_any(g))) {
+#pragma unroll
+            for (int k = 0; k < WPI; ++k) g[k] = div_by_const(g[k], two_sp, rcp2);
+        } else {
+#pragma unroll
+            for (int k = 0; k < WPI; ++k) {
+                const int u = 64 * (c + k) + lane;
+                const float den = (u == 0 || u == L - 1) ? sp : two_sp;
+                g[k] = (u < L && L > 1) ? g[k] / den : 0.f;
+            }
         }
+        if constexpr (NEXT_INNER) {
+            const float* const pe = env.ptr(256 * it + 255 + lane);
+#pragma unroll
+            for (int k = 0; k < WPI; ++k) { ea[k] = pe[Env::STRIDE * (64 * k + 2)]; eb[k] = pe[Env::STRIDE * 64 * k]; }
+        } else if (it + 1 < niter) {                           // clamped indices; the gradient masks u >= L
+#pragma unroll
+            for (int k = 0; k < WPI; ++k) {
+                const int u = 256 * (it + 1) + 64 * k + lane;
+                const int uc = u < L ? u : L - 1;
+                ea[k] = env.at(uc + 1 < L ? uc + 1 : L - 1);   // u = 0: 1;  u = L-1: L-1;  else u+1
+                eb[k] = env.at(uc > 0 ? uc - 1 : 0);           // u = 0: 0;  u = L-1: L-2;  else u-1
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < WPI; ++k) ring[H + 64 * k + lane] = g[k];
+        stof_fft::wave_lds_sync();                             // a lane's reads of its neighbours' gradients follow their stores
+        float sm[WPI] = {0.f, 0.f, 0.f, 0.f};
+        unsigned long long P[WPI] = {0ull, 0ull, 0ull, 0ull}, M[WPI] = {0ull, 0ull, 0ull, 0ull};
+        if (INNER || 256 * it - rad < L) {                     // (an iteration past the row only flushes the pairing)
+            // blurred gradient of sample i = u - rad from the gradients u - 2 rad .. u, four or eight taps at a time for the
+            // WPI words (tap reads are shared by them); the fmaf chain keeps the tap order, i.e. the reference's rounding
+            auto tap_group4 = [&](int j) {
+                const float4 ta = *reinterpret_cast<const float4*>(taps + j);
+#pragma unroll
+                for (int k = 0; k < WPI; ++k) {
+                    const float* rr = r0 + 64 * k + j;
+                    const float g0 = rr[0], g1 = rr[1], g2 = rr[2], g3 = rr[3];
+                    float a = sm[k];
+                    a = fmaf(ta.x, g0, a); a = fmaf(ta.y, g1, a); a = fmaf(ta.z, g2, a); a = fmaf(ta.w, g3, a);
+                    sm[k] = a;
+                }
+                __builtin_amdgcn_sched_barrier(0);             // (keeps the scheduler from requesting every group at once: registers)
+            };
+            auto tap_group = [&](int j) { tap_group4(j); tap_group4(j + 4); };
+            // straight-line code for the two radii the reference uses (rf 10: 11 taps, rf 20: 31 taps)
+            if (ntaps <= 12) { tap_group(0); tap_group4(8); }
+            else if (ntaps <= 32) { tap_group(0); tap_group(8); tap_group(16); tap_group(24); }
+            else for (int j = 0; j < ntaps; j += 8) tap_group(j);
+            if constexpr (INNER) {
+#pragma unroll
+                for (int k = 0; k < WPI; ++k) {
+                    P[k] = __ballot(sm[k] > cf.th_pos);        // grad > thres_pos (:23)
+                    M[k] = __ballot(sm[k] < cf.th_neg);        // grad < thres_neg (:24)
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < WPI; ++k) {
+                    const int i = 64 * (c + k) + lane - rad;
+                    const bool in_row = (i >= 0) && (i < L);
+                    P[k] = __ballot(in_row && sm[k] > cf.th_pos);
+                    M[k] = __ballot(in_row && sm[k] < cf.th_neg);
+                    sm[k] = in_row ? sm[k] : 0.f;
+                }
+            }
+        }
+        sink(c, P, M, sm);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    {                                                          // samples of iteration 0
+#pragma unroll
+        for (int k = 0; k < WPI; ++k) {
+            const int u = 64 * k + lane;
+            const int uc = u < L ? u : L - 1;
+            ea[k] = env.at(uc + 1 < L ? uc + 1 : L - 1);
+            eb[k] = env.at(uc > 0 ? uc - 1 : 0);
+        }
+    }
+    for (int it = 0; it < niter; ++it) {
+        if (it >= 1 && it < n_in) iteration(it, T{}, T{});
+        else if (it >= 1 && it == n_in) iteration(it, T{}, F{});
+        else iteration(it, F{}, F{});
+        batch_end(WPI * (it + 1));                             // (one call site: the pairing behind it is large)
+    }
+}
+
+// 64 iterations of the pairing at a time: lane l holds the edge words (EP, EM) of the word that iteration c0 + l pairs
+// (= word c0 + l - 1, samples 64 (c0 + l - 1) - rad ...); a ballot tells which iterations hold an onset, and the scalar
+// loop visits only those and the stretch behind a pending onset.
+template <class EnvAt>
+__device__ __forceinline__ void pair_lane_words(RowState& st, unsigned long long EP, unsigned long long EM, int c0, int lane,
+                                                const Config& cf, float* __restrict__ out, EnvAt env_at) {
+    const int rad = cf.radius;
+    {
         const unsigned long long has_ep = __ballot(EP != 0), has_em = __ballot(EM != 0);
         st.any_ap |= (has_ep != 0);
         st.any_am |= (has_em != 0);
@@ -297,6 +471,102 @@ __device__ __forceinline__ void pair_stored_words(RowState& st, const unsigned l
             pair_word(st, 64 * (c0 + l - 1) - rad, ep, em, lane, cf, out, env_at);
             ++l;
         }
+    }
+}
+
+// edge-candidate mask of iteration c: bit l <=> sample i = 64 c + l - rad is an edge index, 0 <= i <= L - 2
+__device__ __forceinline__ unsigned long long valid_word(int c, int L, int rad) {
+    int lo = rad - 64 * c, hi = L - 2 + rad - 64 * c;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > 63 ? 63 : hi;
+    if (hi < lo) return 0ull;
+    return (~0ull >> (63 - hi)) & (~0ull << lo);
+}
+
+// Flag words of up to 64 consecutive iterations kept in vector registers: lane l holds (P, M) of iteration c0 + l.
+struct FlagBatch {
+    unsigned plo = 0, phi = 0, mlo = 0, mhi = 0;
+    unsigned long long carry_p = 0, carry_m = 0;               // (P, M) of iteration c0 - 1
+    __device__ __forceinline__ void put(int lane, int idx, unsigned long long P, unsigned long long M) {
+        const bool mine = lane == idx;                         // (v_writelane_b32 takes one scalar operand on this target)
+        plo = mine ? (unsigned)P : plo;
+        phi = mine ? (unsigned)(P >> 32) : phi;
+        mlo = mine ? (unsigned)M : mlo;
+        mhi = mine ? (unsigned)(M >> 32) : mhi;
+    }
+};
+
+// pairs the iterations c0 .. c0 + count - 1 held by `fb` (count <= 64) and moves the carry on
+template <class EnvAt>
+__device__ __forceinline__ void pair_batch(RowState& st, FlagBatch& fb, int c0, int count, int lane, const Config& cf,
+                                           float* __restrict__ out, EnvAt env_at) {
+    const unsigned long long P = ((unsigned long long)fb.phi << 32) | fb.plo, M = ((unsigned long long)fb.mhi << 32) | fb.mlo;
+    const unsigned pp_lo = __shfl_up(fb.plo, 1), pp_hi = __shfl_up(fb.phi, 1), mp_lo = __shfl_up(fb.mlo, 1), mp_hi = __shfl_up(fb.mhi, 1);
+    const unsigned long long Pp = lane ? (((unsigned long long)pp_hi << 32) | pp_lo) : fb.carry_p;
+    const unsigned long long Mp = lane ? (((unsigned long long)mp_hi << 32) | mp_lo) : fb.carry_m;
+    const int c = c0 + lane;
+    unsigned long long EP = 0, EM = 0;
+    if (c >= 1 && lane < count) {                              // an edge at the last lane of a word needs the next word's first flag
+        const unsigned long long Vp = valid_word(c - 1, cf.L, cf.radius);
+        EP = ~Pp & ((Pp >> 1) | (P << 63)) & Vp;
+        EM = ~Mp & ((Mp >> 1) | (M << 63)) & Vp;
+    }
+    pair_lane_words(st, EP, EM, c0, lane, cf, out, env_at);
+    fb.carry_p = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(fb.phi, 63) << 32) | (unsigned)__builtin_amdgcn_readlane(fb.plo, 63);
+    fb.carry_m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(fb.mhi, 63) << 32) | (unsigned)__builtin_amdgcn_readlane(fb.mlo, 63);
+}
+
+// grad_peak_detect of one row with the block streamer: flags into a FlagBatch, pairing every 64 words
+template <class Env>
+__device__ __forceinline__ void detect_row_blocks(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring, int lane,
+                                                  const Env env, float* __restrict__ out, RowState& st) {
+    const int nwords = word_count(cf.L, cf.radius);
+    FlagBatch fb;
+    auto env_at = [&](int i) { return env.at(i); };            // amplitude of a kept peak
+    stream_blocks(cf, taps, ring, lane, env,
+                  [&](int c, const unsigned long long (&P)[WPI], const unsigned long long (&M)[WPI], const float (&)[WPI]) {
+#pragma unroll
+                      for (int k = 0; k < WPI; ++k) fb.put(lane, (c + k) & 63, P[k], M[k]);
+                  },
+                  [&](int next) {                              // batches start at multiples of 64 (WPI divides 64)
+                      if ((next & 63) == 0 || next >= nwords) {
+                          const int c0 = (next - 1) & ~63;
+                          const int count = (next < nwords ? next : nwords) - c0;
+                          if (count > 0) pair_batch(st, fb, c0, count, lane, cf, out, env_at);
+                      }
+                  });
+}
+
+// sums of the blurred gradient of one row (the Q7 pre-pass); lanes outside the row deliver 0
+template <class Env>
+__device__ __forceinline__ void moments_row_blocks(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring, int lane,
+                                                   const Env env, double (&mom)[2]) {
+    stream_blocks(cf, taps, ring, lane, env,
+                  [&](int, const unsigned long long (&)[WPI], const unsigned long long (&)[WPI], const float (&sm)[WPI]) {
+#pragma unroll
+                      for (int k = 0; k < WPI; ++k) {
+                          mom[0] += (double)sm[k];
+                          mom[1] += (double)sm[k] * (double)sm[k];
+                      }
+                  },
+                  [](int) {});
+}
+
+// Pairing of a row from its stored flag words F[3 c + {0, 1, 2}] = (P, M, V) of iteration c, c = 0 .. nwords - 1 (LDS, by
+// one wave), 64 iterations at a time.
+template <class EnvAt>
+__device__ __forceinline__ void pair_stored_words(RowState& st, const unsigned long long* __restrict__ F, int nwords, int lane,
+                                                  const Config& cf, float* __restrict__ out, EnvAt env_at) {
+    for (int c0 = 1; c0 < nwords; c0 += 64) {
+        const int c = c0 + lane;
+        unsigned long long EP = 0, EM = 0;
+        if (c < nwords) {
+            const unsigned long long Pp = F[3 * (c - 1)], Mp = F[3 * (c - 1) + 1], Vp = F[3 * (c - 1) + 2];
+            const unsigned long long P = F[3 * c], M = F[3 * c + 1];
+            EP = ~Pp & ((Pp >> 1) | (P << 63)) & Vp;
+            EM = ~Mp & ((Mp >> 1) | (M << 63)) & Vp;
+        }
+        pair_lane_words(st, EP, EM, c0, lane, cf, out, env_at);
     }
 }
 

@@ -8,8 +8,15 @@ import torch
 from . import _lib
 from .hilbert import hilbert_envelope
 
-_KEEP_BLURRED_MIN_ROWS = 3072        # 12 rows per CU of an MI355X: below that the split rows kernel serves both passes
+_MOMENT_SLOTS = 64     # STOF_MOMENT_SLOTS (include/stofnet_amd.h)
 _CAP = 32          # echoes per row kept by the first pass; rows with more trigger a re-run
+# Waveforms in (toa_detect), row lengths the fused kernels take: up to this many rows the envelope never leaves the chip
+# (explicit threshold: ONE launch, stof_toa_detect; default threshold: stof_toa_moments, then the row kernel on the
+# envelope it kept); larger batches run the envelope kernel and the row kernels, which are faster there -- the fused
+# kernels hold a pair of rows per two waves, eight pairs per CU, and every extra round of pairs costs a full
+# transform + streaming latency.  Measured on the MI355X per batch size: tools/time_gradpeak_paths.py ->
+# profiles/r03_gradpeak_paths.json ([2048, 2000]: 69 vs 84 us per call, [4096, 2000]: 92 vs 88, [32768, 2000]: 485 vs 319).
+_ONE_LAUNCH_MAX_ROWS = 3072
 
 
 def gaussian_kernel_1d(sigma: float, num_sigmas: float = 3.) -> torch.Tensor:
@@ -67,28 +74,32 @@ def _detect(frame_or_env, is_frame, grad_step, threshold, ival, echo_max, group=
     lib = _lib.lib()
     stream = _lib.stream_ptr(x.device)
     emax = int(echo_max) if (echo_max is not None and echo_max != float('inf') and echo_max >= 1) else 0
-    fused = bool(is_frame and threshold is not None and lib.stof_toa_detect_fused_ok(L, radius))
+    fused_ok = bool(is_frame and lib.stof_toa_detect_fused_ok(L, radius))
+    one_launch = fused_ok and n <= _ONE_LAUNCH_MAX_ROWS
+    fused = one_launch and threshold is not None
     env = None
     th_dev = None
-    blurred = None
     with torch.cuda.device(x.device):
         if not fused:
-            env = hilbert_envelope(x, keep_cached=True) if is_frame else x
             if threshold is None:
                 # Q7: (unbiased std of the WHOLE batch tensor) ** 16 * 1.2e13 (models/gradpeak.py:18), formed on the device
                 stats = torch.tensor([0.0, 0.0, float(n * L)], dtype=torch.float64, device=x.device)
-                if n >= _KEEP_BLURRED_MIN_ROWS:
-                    # enough rows for one wave per row: the pre-pass keeps the smoothed gradient and the detection below
-                    # only thresholds and pairs it (rows of the two passes would otherwise be differentiated and blurred twice)
-                    blurred = torch.empty((n, lib.stof_gradpeak_blurred_stride(L, radius)), dtype=torch.float32, device=x.device)
-                    _lib.check(lib.stof_gradpeak_moments_store(_lib.ptr(env), n, L, int(grad_step), _lib.ptr(taps), radius,
-                                                               _lib.ptr(stats), _lib.ptr(blurred), stream), 'stof_gradpeak_moments_store')
+                if one_launch:
+                    # one launch from the waveforms: envelope (kept for the detection below) and the moments of its
+                    # smoothed gradient without the envelope being read back
+                    env = torch.empty_like(x)
+                    partials = torch.empty(_MOMENT_SLOTS * 16, dtype=torch.float64, device=x.device)
+                    _lib.check(lib.stof_toa_moments(_lib.ptr(x), n, L, int(grad_step), _lib.ptr(taps), radius, _lib.ptr(env),
+                                                    _lib.ptr(partials), _lib.ptr(stats), stream), 'stof_toa_moments')
                 else:
+                    env = hilbert_envelope(x, keep_cached=True) if is_frame else x
                     _lib.check(lib.stof_gradpeak_moments(_lib.ptr(env), n, L, int(grad_step), _lib.ptr(taps), radius,
                                                          _lib.ptr(stats), stream), 'stof_gradpeak_moments')
                 _moment_reduce(stats, group)
                 th_dev = torch.empty(1, dtype=torch.float32, device=x.device)
                 _lib.check(lib.stof_gradpeak_threshold(_lib.ptr(stats), _lib.ptr(th_dev), stream), 'stof_gradpeak_threshold')
+            else:
+                env = hilbert_envelope(x, keep_cached=True) if is_frame else x
 
         def run(cap):
             echoes = torch.empty((n, cap, 3), dtype=torch.float32, device=x.device)
@@ -100,10 +111,6 @@ def _detect(frame_or_env, is_frame, grad_step, threshold, ival, echo_max, group=
                 code = lib.stof_toa_detect(_lib.ptr(x), n, L, int(grad_step), _lib.ptr(taps), radius, th, ival[0], ival[1],
                                            emax, _lib.ptr(echoes), cap, _lib.ptr(reduced), _lib.ptr(counts),
                                            _lib.ptr(flags), None, stream)
-            elif blurred is not None:
-                code = lib.stof_grad_peak_detect_blurred(_lib.ptr(env), _lib.ptr(blurred), n, L, radius, th, _lib.ptr(th_dev),
-                                                         ival[0], ival[1], emax, _lib.ptr(echoes), cap, _lib.ptr(reduced),
-                                                         _lib.ptr(counts), _lib.ptr(flags), stream)
             else:
                 code = lib.stof_grad_peak_detect(_lib.ptr(env), n, L, int(grad_step), _lib.ptr(taps), radius, th,
                                                  _lib.ptr(th_dev), ival[0], ival[1], emax, _lib.ptr(echoes), cap,

@@ -552,24 +552,72 @@ def test_gradpeak_1024_rows_exact_vs_reference(dev, rf, thn, th):
 
 
 @pytest.mark.parametrize('rf', [10, 20])
-def test_gradpeak_default_threshold_with_kept_blurred_gradient(dev, rf, monkeypatch):
-    """Large batches keep the smoothed gradient of the moments pre-pass and only threshold / pair it afterwards
-    (stof_gradpeak_moments_store + stof_grad_peak_detect_blurred): same result as differentiating and blurring twice,
-    and the reference's indices on the 1024-row golden (rows the float64 oracle marks borderline excepted)."""
+def test_gradpeak_default_threshold_paths_agree(dev, rf):
+    """The default threshold (Q7) three ways through the C ABI: (a) toa_detect's own path (rf 10: stof_toa_moments from
+    the waveforms + stof_grad_peak_detect; rf 20: envelope kernel + stof_gradpeak_moments + detect), (b) moments of the
+    envelope rows (stof_gradpeak_moments), (c) the pre-pass that keeps the smoothed gradient and the detection that only
+    thresholds and pairs it (stof_gradpeak_moments_store + stof_grad_peak_detect_blurred).  Same threshold bits, same
+    echoes, and the reference's indices on the 1024-row golden."""
     import stofnet_amd.gradpeak as gp
-    from stofnet_amd import toa_detect
+    from stofnet_amd import _lib, toa_detect
+    from stofnet_amd.hilbert import hilbert_envelope
+    lib = _lib.lib()
     g = golden('f9_gradpeak_1024')
     L, seed = int(g[f'L_rf{rf}']), int(g[f'seed_rf{rf}'])
     x = torch.from_numpy(synth.synth_echo(1024, L, seed=seed, noise=0.01)).to(dev).squeeze(1)
     a = toa_detect(x, threshold=None, rescale_factor=rf).cpu().numpy()
-    monkeypatch.setattr(gp, '_KEEP_BLURRED_MIN_ROWS', 1)
-    b = toa_detect(x, threshold=None, rescale_factor=rf).cpu().numpy()
-    assert a.shape == b.shape and np.array_equal(a, b)
     idx = g[f'idx_rf{rf}_thnone']
-    differs = (b[..., :2] != idx).any(axis=(1, 2))
+    differs = (a[..., :2] != idx).any(axis=(1, 2))
     assert differs.sum() == 0, f'rows {np.nonzero(differs)[0][:8]} differ from the reference'
     e3 = gp.GradPeak(threshold=None, rescale_factor=rf, echo_max=3, onset_opt=False)(x.unsqueeze(1)).cpu().numpy()
-    assert np.array_equal(e3[~differs], g[f'em3_rf{rf}_thnone'][~differs])
+    assert np.array_equal(e3, g[f'em3_rf{rf}_thnone'])
+
+    n, gs, st = x.shape[0], rf // 6 * 5, _lib.stream_ptr(dev)
+    taps = gp.gaussian_kernel_1d((gs * 2 - 1) / 6).to(dev).float()
+    rad = (taps.numel() - 1) // 2
+    env = hilbert_envelope(x)
+
+    def threshold_of(stats):
+        th = torch.empty(1, device=dev)
+        _lib.check(lib.stof_gradpeak_threshold(_lib.ptr(stats), _lib.ptr(th), st), 'threshold')
+        return th
+
+    stats_b = torch.tensor([0.0, 0.0, float(n * L)], dtype=torch.float64, device=dev)
+    _lib.check(lib.stof_gradpeak_moments(_lib.ptr(env), n, L, gs, _lib.ptr(taps), rad, _lib.ptr(stats_b), st), 'moments')
+    stats_c = torch.tensor([0.0, 0.0, float(n * L)], dtype=torch.float64, device=dev)
+    blurred = torch.empty((n, lib.stof_gradpeak_blurred_stride(L, rad)), device=dev)
+    _lib.check(lib.stof_gradpeak_moments_store(_lib.ptr(env), n, L, gs, _lib.ptr(taps), rad, _lib.ptr(stats_c), _lib.ptr(blurred), st), 'store')
+    th_b, th_c = threshold_of(stats_b), threshold_of(stats_c)
+    assert torch.allclose(stats_b, stats_c, rtol=1e-12, atol=0) and th_b.item() == th_c.item()
+    if lib.stof_toa_detect_fused_ok(L, rad):
+        stats_a = torch.tensor([0.0, 0.0, float(n * L)], dtype=torch.float64, device=dev)
+        env_a = torch.empty_like(x)
+        partials = torch.empty(64 * 16, dtype=torch.float64, device=dev)
+        _lib.check(lib.stof_toa_moments(_lib.ptr(x), n, L, gs, _lib.ptr(taps), rad, _lib.ptr(env_a), _lib.ptr(partials),
+                                        _lib.ptr(stats_a), st), 'toa_moments')
+        # the fused kernel's envelope comes from a different FFT plan than stof_hilbert's: values within ENV_TOL, moments
+        # to ~1e-6, and the threshold -- a 16th power -- to ~1e-4 relative
+        assert (env_a - env).abs().max().item() < ENV_TOL
+        assert torch.allclose(stats_a, stats_b, rtol=1e-5, atol=0)
+        assert threshold_of(stats_a).item() == pytest.approx(th_b.item(), rel=1e-3)      # (0 on this data: std**16 underflows)
+    cap = a.shape[1] + 4
+    outs = []
+    for use_blurred in (False, True):
+        e = torch.zeros(n, cap, 3, device=dev)
+        c = torch.zeros(n, dtype=torch.int32, device=dev)
+        f = torch.zeros(2, dtype=torch.int32, device=dev)
+        if use_blurred:
+            code = lib.stof_grad_peak_detect_blurred(_lib.ptr(env), _lib.ptr(blurred), n, L, rad, 0.0, _lib.ptr(th_c), rf, 50 * rf, 0,
+                                                     _lib.ptr(e), cap, None, _lib.ptr(c), _lib.ptr(f), st)
+        else:
+            code = lib.stof_grad_peak_detect(_lib.ptr(env), n, L, gs, _lib.ptr(taps), rad, 0.0, _lib.ptr(th_b), rf, 50 * rf, 0,
+                                             _lib.ptr(e), cap, None, _lib.ptr(c), _lib.ptr(f), st)
+        _lib.check(code, 'detect')
+        outs.append((e.cpu().numpy(), c.cpu().numpy(), f.cpu().numpy()))
+    for u, v in zip(outs[0], outs[1]):
+        assert np.array_equal(u, v)
+    kmax = int(outs[0][2][1])
+    assert kmax == a.shape[1] and np.array_equal(outs[0][0][:, :kmax, :2], idx)
 
 
 @pytest.mark.parametrize('W', [1, 2, 4])

@@ -97,9 +97,12 @@ CASES = {
     'hilbert_2048x15360': lambda: case_hilbert(2048, 15360),
     'hilbert_1024x20000': lambda: case_hilbert(1024, 20000),
     'hilbert_512x30720': lambda: case_hilbert(512, 30720),
-    'gradpeak_fused_4096x2000_rf10_th1em3': lambda: case_gradpeak(4096, 2000, 10, 1e-3),
-    'gradpeak_fused_32768x2000_rf10_th1em3': lambda: case_gradpeak(32768, 2000, 10, 1e-3),
+    # (row counts up to gradpeak._ONE_LAUNCH_MAX_ROWS take the fused kernels, larger batches envelope kernel + row kernels)
+    'gradpeak_th1em3_2048x2000_rf10': lambda: case_gradpeak(2048, 2000, 10, 1e-3),
+    'gradpeak_th1em3_4096x2000_rf10': lambda: case_gradpeak(4096, 2000, 10, 1e-3),
+    'gradpeak_th1em3_32768x2000_rf10': lambda: case_gradpeak(32768, 2000, 10, 1e-3),
     'gradpeak_chirp_4096x2000_rf10_th1em3': lambda: case_gradpeak(4096, 2000, 10, 1e-3, chirp=True),
+    'gradpeak_default_th_2048x2000_rf10': lambda: case_gradpeak(2048, 2000, 10, None),
     'gradpeak_default_th_4096x2000_rf10': lambda: case_gradpeak(4096, 2000, 10, None),
     'gradpeak_unfused_4096x4000_rf20_th1em3': lambda: case_gradpeak(4096, 4000, 20, 1e-3),
     'gradpeak_long_512x30720_rf20_th1em4': lambda: case_gradpeak(512, 30720, 20, 1e-4, long_rows=True),

@@ -75,16 +75,10 @@ def margin(sm_row, thp):
     return float(min(np.abs(sm_row - thp).min(), np.abs(sm_row + thp / 4).min()))
 
 
-def one_case(name, frame, rf, th, ref_idx, variant=None):
+def one_case(name, frame, rf, th, ref_idx):
     dev = torch.device('cuda:0')
     x = torch.from_numpy(frame).to(dev)
-    keep = gp._KEEP_BLURRED_MIN_ROWS
-    if variant == 'kept_blurred':
-        gp._KEEP_BLURRED_MIN_ROWS = 1
-    try:
-        got = toa_detect(x, threshold=th, rescale_factor=rf).cpu().numpy()
-    finally:
-        gp._KEEP_BLURRED_MIN_ROWS = keep
+    got = toa_detect(x, threshold=th, rescale_factor=rf).cpu().numpy()
     g_rows = rows_of(got)
     exact, sm, thp = exact_pipeline(frame.astype(np.float64), rf, th)
     scale = float(np.abs(sm).max())
@@ -117,8 +111,6 @@ def main():
         frame = synth.synth_echo(1024, L, seed=seed, noise=0.01)[:, 0]
         for thn, th in (('1em3', 1e-3), ('none', None)):
             out['cases'].append(one_case(f'f9_gradpeak_1024 rf{rf} th{thn}', frame, rf, th, golden[f'idx_rf{rf}_th{thn}']))
-        out['cases'].append(one_case(f'f9_gradpeak_1024 rf{rf} thnone, kept smoothed gradient', frame, rf, None,
-                                     golden[f'idx_rf{rf}_thnone'], variant='kept_blurred'))
     frame = synth.synth_echo(4096, 2000, seed=77, noise=0.01)[:, 0]
     out['cases'].append(one_case('4096 rows (seed 77) rf10 th1e-3, no reference golden', frame, 10, 1e-3, None))
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)

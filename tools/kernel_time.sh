@@ -14,7 +14,7 @@ tot = collections.defaultdict(list)
 for f in glob.glob(sys.argv[2] + '/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         tot[r['Kernel_Name'].replace('void (anonymous namespace)::','').split('(')[0][:70]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-for k, v in sorted(tot.items(), key=lambda kv: -sum(kv[1]))[:3]:
+for k, v in sorted(tot.items(), key=lambda kv: -sum(kv[1]))[:6]:
     v = sorted(v)
     print(f"{sys.argv[1]:28s} {k:72s} n={len(v):3d} median {v[len(v)//2]:8.2f} us  min {v[0]:8.2f}")
 PY
