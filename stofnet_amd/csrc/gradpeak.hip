@@ -110,23 +110,18 @@ __global__ __launch_bounds__(64 * WAVES) void gradpeak_rows_kernel(const float* 
 
 // ----------------------------------------------------------------------------------------------------------------
 // grad_peak_detect on envelope rows in HBM, work-group of 4 waves: each row is streamed by W = 1, 2 or 4 waves that
-// split its iterations (a wave refills its gradient ring by running warm_words extra iterations), so few long rows
-// still fill the chip.  The envelope reaches the streaming loop through LDS: a wave copies SPLIT_CHUNK + 1 words of
-// its stretch with coalesced loads that are in flight together (the next chunk is requested before the current one is
-// streamed), instead of waiting for one HBM round trip per 64 samples.  The flag words of the row go to LDS; after a
-// barrier the first wave of the row pairs them (pair_stored_words).  MOMENTS: the sums of the default threshold (Q7).
+// split its iterations (a wave that starts inside the row runs one extra iteration to fill its gradient history), so
+// few long rows still fill the chip.  The flag words of the row go to LDS; after a barrier the first wave of the row
+// pairs them (pair_stored_words).  MOMENTS: the sums of the default threshold (Q7).
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int SPLIT_CHUNK = 8;                                   // iterations per LDS chunk
-constexpr int SPLIT_BUF = (SPLIT_CHUNK + 1) * 64 + 2;            // floats of the chunk buffer: one sample before, one word + one sample after
-__host__ __device__ inline int split_wave_floats(int radius) { return stof_gp::ring_floats(radius) + SPLIT_BUF; }
 __host__ __device__ inline int split_flag_offset(int radius) {   // floats before the flag words (8-byte aligned)
-    const int f = stof_gp::TAPS_LDS + 4 * split_wave_floats(radius);
+    const int f = stof_gp::TAPS_LDS + 4 * stof_gp::block_buf_floats(radius);
     return f + (f & 1);
 }
 inline size_t split_lds_bytes(int L, int radius, int W) {
-    // flag words of the rows of one work-group; the MOMENTS variant reuses the region for 8 doubles (64 B), which a
-    // short row (W = 4, two words: 48 B) would not cover
-    size_t flag_bytes = (size_t)(4 / W) * 3 * stof_gp::word_count(L, radius) * 8;
+    // flag words (P, M, V) of every iteration's four words, for the rows of one work-group; the MOMENTS variant reuses
+    // the region for 8 doubles
+    size_t flag_bytes = (size_t)(4 / W) * 3 * stof_gp::block_iterations(L, radius) * stof_gp::WPI * 8;
     if (flag_bytes < 64) flag_bytes = 64;
     return (size_t)split_flag_offset(radius) * 4 + flag_bytes;
 }
@@ -139,62 +134,55 @@ __global__ __launch_bounds__(256) void gradpeak_split_kernel(const float* __rest
                                                              double* __restrict__ stats, int W) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L = cf.L, rad = cf.radius, nwords = stof_gp::word_count(L, rad), RPW = 4 / W;
+    const int L = cf.L, rad = cf.radius, nwords = stof_gp::word_count(L, rad), niter = stof_gp::block_iterations(L, rad), RPW = 4 / W;
     float* const tp = lds_f;
-    float* const ring = tp + stof_gp::TAPS_LDS + wave * split_wave_floats(rad);
-    float* const buf = ring + stof_gp::ring_floats(rad);
+    float* const ring = tp + stof_gp::TAPS_LDS + wave * stof_gp::block_buf_floats(rad);
     stof_gp::stage_taps(tp, taps, rad, tid, 256);
     if (th_dev != nullptr) {                                   // default threshold computed on the device (Q7)
         cf.th_pos = *th_dev;
         cf.th_neg = -cf.th_pos / 4.0f;                          // models/gradpeak.py:19
     }
     const int slot = wave / W, part = wave % W;                  // row slot of this wave, its share of the row's iterations
-    unsigned long long* const F = reinterpret_cast<unsigned long long*>(tp + split_flag_offset(rad)) + (size_t)slot * 3 * nwords;
-    // iterations [p_first, p_last] of this wave (contiguous, near-equal shares); the stream starts warm_words earlier
-    const int per = (nwords + W - 1) / W, p_first = part * per, p_last = (p_first + per < nwords ? p_first + per : nwords) - 1;
-    int s_first = p_first - stof_gp::warm_words(rad);
-    if (s_first < 0) s_first = 0;
+    unsigned long long* const F = reinterpret_cast<unsigned long long*>(tp + split_flag_offset(rad)) + (size_t)slot * 3 * niter * stof_gp::WPI;
+    // iterations [it_b, it_e) of this wave (contiguous, near-equal shares)
+    const int per = (niter + W - 1) / W, it_b = part * per, it_e = it_b + per < niter ? it_b + per : niter;
     double mom[2] = {0.0, 0.0};
     __syncthreads();
     for (long long row0 = (long long)blockIdx.x * RPW; row0 < N; row0 += (long long)gridDim.x * RPW) {
         const long long row = row0 + slot;
-        if (row < N && p_first <= p_last) {
-            const float* e = env + row * (long long)L;
-            float nxt[SPLIT_CHUNK + 2];
-            // the chunk of the iterations c0 .. c0 + SPLIT_CHUNK - 1 holds the samples 64 c0 - 1 .. 64 (c0 + SPLIT_CHUNK + 1):
-            // one sample before (central difference of the first sample), one word + one sample after (the stream fetches
-            // one iteration ahead)
-            auto request = [&](int c0) {
+        const float* const e = env + row * (long long)L;
+        if (row < N && it_b < it_e) {
+            if constexpr (MOMENTS) {
+                stof_gp::stream_blocks(cf, tp, ring, lane, stof_gp::EnvRow{e},
+                                       [&](int, const unsigned long long (&)[stof_gp::WPI], const unsigned long long (&)[stof_gp::WPI],
+                                           const float (&sm)[stof_gp::WPI]) {
 #pragma unroll
-                for (int k = 0; k < SPLIT_CHUNK + 2; ++k) {
-                    int sidx = 64 * c0 - 1 + 64 * k + lane;
-                    sidx = sidx < 0 ? 0 : (sidx > L - 1 ? L - 1 : sidx);
-                    nxt[k] = (k < SPLIT_CHUNK + 1 || lane < 2) ? e[sidx] : 0.f;
-                }
-            };
-            request(s_first);
-            for (int c0 = s_first; c0 <= p_last; c0 += SPLIT_CHUNK) {
-                stof_fft::wave_lds_sync();                        // the previous chunk has been streamed
+                                           for (int k = 0; k < stof_gp::WPI; ++k) {
+                                               mom[0] += (double)sm[k];
+                                               mom[1] += (double)sm[k] * (double)sm[k];
+                                           }
+                                       },
+                                       [](int) {}, it_b, it_e);
+            } else {
+                stof_gp::FlagBatch fb;
+                const int w_b = stof_gp::WPI * it_b, w_e = stof_gp::WPI * it_e;
+                stof_gp::stream_blocks(cf, tp, ring, lane, stof_gp::EnvRow{e},
+                                       [&](int c, const unsigned long long (&P)[stof_gp::WPI], const unsigned long long (&M)[stof_gp::WPI],
+                                           const float (&)[stof_gp::WPI]) {
 #pragma unroll
-                for (int k = 0; k < SPLIT_CHUNK + 1; ++k) buf[64 * k + lane] = nxt[k];
-                if (lane < 2) buf[64 * (SPLIT_CHUNK + 1) + lane] = nxt[SPLIT_CHUNK + 1];
-                stof_fft::wave_lds_sync();
-                if (c0 + SPLIT_CHUNK <= p_last) request(c0 + SPLIT_CHUNK);       // in flight while this chunk is streamed
-                const int c1 = c0 + SPLIT_CHUNK - 1 < p_last ? c0 + SPLIT_CHUNK - 1 : p_last;
-                const int base = 64 * c0 - 1;
-                stof_gp::stream_words<1>(
-                    cf, tp, ring, lane,
-                    [&](int u, float (&v)[1]) { const int j = u - base; v[0] = buf[j < 0 ? 0 : j]; },   // (j < 0 only for masked samples)
-                    c0, c1, c0 == s_first,
-                    [&](int c, int, unsigned long long P, unsigned long long M, unsigned long long V, float sm) {
-                        if (c < p_first) return;                  // refilling the ring
-                        if (MOMENTS) {
-                            mom[0] += (double)sm;
-                            mom[1] += (double)sm * (double)sm;
-                        } else if (lane == 0) {
-                            F[3 * c] = P; F[3 * c + 1] = M; F[3 * c + 2] = V;
-                        }
-                    });
+                                           for (int k = 0; k < stof_gp::WPI; ++k) fb.put(lane, (c + k) & 63, P[k], M[k]);
+                                       },
+                                       [&](int next) {             // 64 words collected (or the share is done): lane l stores word c0 + l
+                                           if ((next & 63) == 0 || next >= w_e) {
+                                               const int c = ((next - 1) & ~63) + lane;
+                                               if (c >= w_b && c < next) {
+                                                   F[3 * c] = ((unsigned long long)fb.phi << 32) | fb.plo;
+                                                   F[3 * c + 1] = ((unsigned long long)fb.mhi << 32) | fb.mlo;
+                                                   F[3 * c + 2] = stof_gp::valid_word(c, L, rad);
+                                               }
+                                           }
+                                       },
+                                       it_b, it_e);
             }
         }
         if (!MOMENTS) {
@@ -202,7 +190,6 @@ __global__ __launch_bounds__(256) void gradpeak_split_kernel(const float* __rest
             if (row < N && part == 0) {
                 float* const out = echoes + row * cf.cap * 3;
                 RowState st;
-                const float* e = env + row * (long long)L;
                 stof_gp::pair_stored_words(st, F, nwords, lane, cf, out, [&](int i) { return e[i]; });
                 stof_gp::finish_row(st, cf, row, out, reduced, counts, flags, lane);
             }

@@ -324,9 +324,12 @@ struct EnvPairLds {                              // row r of a pair interleaved 
 // The kernels are bound by the number of vector instructions they issue (4 waves per SIMD, every lane busy), so an
 // iteration whose 256 samples lie inside the row -- all but the first and the last one or two -- runs a form without
 // index clamps, end-of-row masks and one-sided differences (wave-uniform choice).
+//   [it_begin, it_end)     : iterations to deliver (default: the whole row).  A stream that starts inside the row runs
+//                            iteration it_begin - 1 first to fill the gradient history (block_hist <= 256) and delivers
+//                            nothing for it.
 template <class Env, class Sink, class BatchEnd>
 __device__ __forceinline__ void stream_blocks(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring, int lane,
-                                              const Env env, Sink sink, BatchEnd batch_end) {
+                                              const Env env, Sink sink, BatchEnd batch_end, const int it_begin = 0, const int it_end = -1) {
     static_assert(WPI == 4, "div_unsafe_any and the history writes assume four words per iteration");
 #if defined(__HIP_DEVICE_COMPILE__)
     // The clamped sample indices of the first and last iterations depend on the lane and the row length only; left to
@@ -341,6 +344,7 @@ __device__ __forceinline__ void stream_blocks(const Config& cf, const float* __r
     // Iteration `it` covers the samples u = 256 it .. 256 it + 255 (gradients) and i = u - rad (blurred values, flags).
     // Iterations 1 .. n_in have every u in 1 .. L - 2 (central differences, no clamps) and every i in 0 .. L - 1.
     const int n_in = L >= 513 ? (L - 257) / 256 : 0;
+    const int it_stop = (it_end < 0 || it_end > niter) ? niter : it_end, it0 = it_begin > 0 ? it_begin - 1 : 0;
     float ea[WPI], eb[WPI];
     float g[WPI] = {0.f, 0.f, 0.f, 0.f};
     const float* const r0 = ring + (H - 2 * rad + lane);
@@ -372,7 +376,7 @@ __device__ __forceinline__ void stream_blocks(const Config& cf, const float* __r
             const float* const pe = env.ptr(256 * it + 255 + lane);
 #pragma unroll
             for (int k = 0; k < WPI; ++k) { ea[k] = pe[Env::STRIDE * (64 * k + 2)]; eb[k] = pe[Env::STRIDE * 64 * k]; }
-        } else if (it + 1 < niter) {                           // clamped indices; the gradient masks u >= L
+        } else if (it + 1 < it_stop) {                         // clamped indices; the gradient masks u >= L
 #pragma unroll
             for (int k = 0; k < WPI; ++k) {
                 const int u = 256 * (it + 1) + 64 * k + lane;
@@ -423,24 +427,24 @@ __device__ __forceinline__ void stream_blocks(const Config& cf, const float* __r
                 }
             }
         }
-        sink(c, P, M, sm);
+        if (it >= it_begin) sink(c, P, M, sm);
     };
     using T = std::true_type;
     using F = std::false_type;
-    {                                                          // samples of iteration 0
+    {                                                          // samples of the first iteration
 #pragma unroll
         for (int k = 0; k < WPI; ++k) {
-            const int u = 64 * k + lane;
+            const int u = 256 * it0 + 64 * k + lane;
             const int uc = u < L ? u : L - 1;
             ea[k] = env.at(uc + 1 < L ? uc + 1 : L - 1);
             eb[k] = env.at(uc > 0 ? uc - 1 : 0);
         }
     }
-    for (int it = 0; it < niter; ++it) {
-        if (it >= 1 && it < n_in) iteration(it, T{}, T{});
-        else if (it >= 1 && it == n_in) iteration(it, T{}, F{});
+    for (int it = it0; it < it_stop; ++it) {
+        if (it >= 1 && it < n_in && it + 1 < it_stop) iteration(it, T{}, T{});
+        else if (it >= 1 && it <= n_in) iteration(it, T{}, F{});
         else iteration(it, F{}, F{});
-        batch_end(WPI * (it + 1));                             // (one call site: the pairing behind it is large)
+        if (it >= it_begin) batch_end(WPI * (it + 1));         // (one call site: the pairing behind it is large)
     }
 }
 
