@@ -74,9 +74,9 @@ __global__ __launch_bounds__(64 * WAVES) void gradpeak_rows_kernel(const float* 
             continue;
         }
         if constexpr (MOMENTS) {
-            stof_gp::moments_row_blocks(cf, tp, ring, lane, stof_gp::EnvRow{e}, mom);
+            stof_gp::moments_row_blocks(cf, tp, ring, lane, stof_gp::EnvRow{e}, mom, taps);
         } else {
-            stof_gp::detect_row_blocks(cf, tp, ring, lane, stof_gp::EnvRow{e}, out[0], st[0]);
+            stof_gp::detect_row_blocks(cf, tp, ring, lane, stof_gp::EnvRow{e}, out[0], st[0], taps);
             stof_gp::finish_row(st[0], cf, row, out[0], reduced, counts, flags, lane, true);
             kmax = st[0].nout > kmax ? st[0].nout : kmax;
         }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void gradpeak_split_kernel(const float* __rest
                                                mom[1] += (double)sm[k] * (double)sm[k];
                                            }
                                        },
-                                       [](int) {}, it_b, it_e);
+                                       [](int) {}, taps, it_b, it_e);
             } else {
                 stof_gp::FlagBatch fb;
                 const int w_b = stof_gp::WPI * it_b, w_e = stof_gp::WPI * it_e;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void gradpeak_split_kernel(const float* __rest
                                                }
                                            }
                                        },
-                                       it_b, it_e);
+                                       taps, it_b, it_e);
             }
         }
         if (!MOMENTS) {
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void toa_fused_kernel(const FusedParams p) 
             } else {
                 float* const out = p.echoes + (row + r) * p.cf.cap * 3;
                 RowState st;
-                stof_gp::detect_row_blocks(p.cf, tp, ring, lane, env, out, st);
+                stof_gp::detect_row_blocks(p.cf, tp, ring, lane, env, out, st);      // (word-form blur: the blocked one costs these kernels a wave per SIMD)
                 GP_STAMP(3);
                 stof_gp::finish_row(st, p.cf, row + r, out, p.reduced, p.counts, p.flags, lane);
                 GP_STAMP(4);
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(64 * WPP * PPW) void toa_fused_ct_kernel(const Fuse
             } else {
                 float* const out = p.echoes + (row + r) * p.cf.cap * 3;
                 RowState st;
-                stof_gp::detect_row_blocks(p.cf, tp, ring, lane, env, out, st);
+                stof_gp::detect_row_blocks(p.cf, tp, ring, lane, env, out, st);      // (word-form blur: the blocked one costs these kernels a wave per SIMD)
                 stof_gp::finish_row(st, p.cf, row + r, out, p.reduced, p.counts, p.flags, lane);
             }
         }

@@ -324,12 +324,15 @@ struct EnvPairLds {                              // row r of a pair interleaved 
 // The kernels are bound by the number of vector instructions they issue (4 waves per SIMD, every lane busy), so an
 // iteration whose 256 samples lie inside the row -- all but the first and the last one or two -- runs a form without
 // index clamps, end-of-row masks and one-sided differences (wave-uniform choice).
+//   taps_g                 : the taps in global memory (optional): rad 15 (rf 20) then takes the blocked blur below, whose
+//                            taps are scalar operands
 //   [it_begin, it_end)     : iterations to deliver (default: the whole row).  A stream that starts inside the row runs
 //                            iteration it_begin - 1 first to fill the gradient history (block_hist <= 256) and delivers
 //                            nothing for it.
 template <class Env, class Sink, class BatchEnd>
 __device__ __forceinline__ void stream_blocks(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring, int lane,
-                                              const Env env, Sink sink, BatchEnd batch_end, const int it_begin = 0, const int it_end = -1) {
+                                              const Env env, Sink sink, BatchEnd batch_end, const float* __restrict__ taps_g = nullptr,
+                                              const int it_begin = 0, const int it_end = -1) {
     static_assert(WPI == 4, "div_unsafe_any and the history writes assume four words per iteration");
 #if defined(__HIP_DEVICE_COMPILE__)
     // The clamped sample indices of the first and last iterations depend on the lane and the row length only; left to
@@ -391,8 +394,37 @@ __device__ __forceinline__ void stream_blocks(const Config& cf, const float* __r
         float sm[WPI] = {0.f, 0.f, 0.f, 0.f};
         unsigned long long P[WPI] = {0ull, 0ull, 0ull, 0ull}, M[WPI] = {0ull, 0ull, 0ull, 0ull};
         if (INNER || 256 * it - rad < L) {                     // (an iteration past the row only flushes the pairing)
-            // blurred gradient of sample i = u - rad from the gradients u - 2 rad .. u, four or eight taps at a time for the
-            // WPI words (tap reads are shared by them); the fmaf chain keeps the tap order, i.e. the reference's rounding
+            // Blurred gradient of sample i = u - rad from the gradients u - 2 rad .. u; the fmaf chain keeps the tap order,
+            // i.e. the reference's rounding.
+            // Blocked form (rad 15): lane l takes the four consecutive outputs 4 l .. 4 l + 3 of the iteration; their
+            // 2 rad + 4 gradients arrive as NV aligned 16-byte reads -- 9 floats of LDS traffic per output where the
+            // word form below reads 2 rad + 1 (the blur of rf 20 was LDS-bandwidth bound: 35 of the row kernel's 53 us on
+            // [4096, 4000]) -- and the taps are scalar operands.  The four results go back through the (now dead) buffer
+            // to reach the word layout the flags need.
+            auto blur_blocked = [&](auto rad_c) {
+                constexpr int R = decltype(rad_c)::value, B = 64 - 2 * R, S = B & 3, BA = B - S, NV = (S + 4 + 2 * R + 3) / 4;
+                float w[4 * NV];
+                const float4* const src = reinterpret_cast<const float4*>(ring + BA + 4 * lane);
+#pragma unroll
+                for (int m = 0; m < NV; ++m) {
+                    const float4 v = src[m];
+                    w[4 * m] = v.x; w[4 * m + 1] = v.y; w[4 * m + 2] = v.z; w[4 * m + 3] = v.w;
+                }
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j <= 2 * R; ++j) {
+                    const float t = taps_g[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = fmaf(t, w[S + e + j], a[e]);
+                }
+                stof_fft::wave_lds_sync();                     // every lane has its window
+                *reinterpret_cast<float4*>(ring + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
+                stof_fft::wave_lds_sync();
+#pragma unroll
+                for (int k = 0; k < WPI; ++k) sm[k] = ring[64 * k + lane];
+            };
+            // Word form (any radius): lane l takes output 64 k + l of each word k, four or eight taps at a time for the WPI
+            // words (tap reads from the LDS image are shared by them).
             auto tap_group4 = [&](int j) {
                 const float4 ta = *reinterpret_cast<const float4*>(taps + j);
 #pragma unroll
@@ -406,8 +438,10 @@ __device__ __forceinline__ void stream_blocks(const Config& cf, const float* __r
                 __builtin_amdgcn_sched_barrier(0);             // (keeps the scheduler from requesting every group at once: registers)
             };
             auto tap_group = [&](int j) { tap_group4(j); tap_group4(j + 4); };
-            // straight-line code for the two radii the reference uses (rf 10: 11 taps, rf 20: 31 taps)
-            if (ntaps <= 12) { tap_group(0); tap_group4(8); }
+            // (measured: rad 15 -- [512, 30720] split kernel 68.6 -> 61.8 us, [4096, 4000] row kernel 52.4 -> 51.1; for rad 5
+            // the word form's 12 reads are no dearer and the fused kernels lose to the extra registers: 35.8 -> 48.3 us)
+            if (taps_g != nullptr && rad == 15) blur_blocked(std::integral_constant<int, 15>{});
+            else if (ntaps <= 12) { tap_group(0); tap_group4(8); }
             else if (ntaps <= 32) { tap_group(0); tap_group(8); tap_group(16); tap_group(24); }
             else for (int j = 0; j < ntaps; j += 8) tap_group(j);
             if constexpr (INNER) {
@@ -523,7 +557,8 @@ __device__ __forceinline__ void pair_batch(RowState& st, FlagBatch& fb, int c0, 
 // grad_peak_detect of one row with the block streamer: flags into a FlagBatch, pairing every 64 words
 template <class Env>
 __device__ __forceinline__ void detect_row_blocks(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring, int lane,
-                                                  const Env env, float* __restrict__ out, RowState& st) {
+                                                  const Env env, float* __restrict__ out, RowState& st,
+                                                  const float* __restrict__ taps_g = nullptr) {
     const int nwords = word_count(cf.L, cf.radius);
     FlagBatch fb;
     auto env_at = [&](int i) { return env.at(i); };            // amplitude of a kept peak
@@ -538,13 +573,14 @@ __device__ __forceinline__ void detect_row_blocks(const Config& cf, const float*
                           const int count = (next < nwords ? next : nwords) - c0;
                           if (count > 0) pair_batch(st, fb, c0, count, lane, cf, out, env_at);
                       }
-                  });
+                  },
+                  taps_g);
 }
 
 // sums of the blurred gradient of one row (the Q7 pre-pass); lanes outside the row deliver 0
 template <class Env>
 __device__ __forceinline__ void moments_row_blocks(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring, int lane,
-                                                   const Env env, double (&mom)[2]) {
+                                                   const Env env, double (&mom)[2], const float* __restrict__ taps_g = nullptr) {
     stream_blocks(cf, taps, ring, lane, env,
                   [&](int, const unsigned long long (&)[WPI], const unsigned long long (&)[WPI], const float (&sm)[WPI]) {
 #pragma unroll
@@ -553,7 +589,7 @@ __device__ __forceinline__ void moments_row_blocks(const Config& cf, const float
                           mom[1] += (double)sm[k] * (double)sm[k];
                       }
                   },
-                  [](int) {});
+                  [](int) {}, taps_g);
 }
 
 // Pairing of a row from its stored flag words F[3 c + {0, 1, 2}] = (P, M, V) of iteration c, c = 0 .. nwords - 1 (LDS, by
