@@ -305,6 +305,16 @@ int stof_train_pool(const float* c, float* pooled, uint8_t* arg, int64_t N, int6
  * pooled value, which is all the leaky-ReLU derivative needs (the fused forward below never materialises c). */
 int stof_train_pool_bwd(const float* gpool, const uint8_t* arg, const float* c, const float* pooled, float* gc, int64_t N,
                         int64_t L, int64_t P, int32_t C, int32_t scale, void* stream);
+
+/* SemiGlobalBlock backward, contract_conv's weight / bias gradient straight from the pool's SPARSE gradient (one non-zero
+ * row per (waveform, window, channel)): dw[C][64][5], db[C] = out_scale * the gradient that stof_train_pool_bwd +
+ * stof_train_wgrad(a1, gc, cin 64, cout C, K 5) produce, without the dense [N, L, C] tensor.  gpool / arg / pooled[N, P, C]
+ * as for stof_train_pool_bwd, a1[N, L, 64] the convolution's input.  STOF_ERR_UNSUPPORTED when C is not a multiple of 128
+ * or scale > 92 (the caller then takes the dense route).                                                            */
+size_t stof_train_sgb_wgrad_workspace_bytes(int32_t C);
+int stof_train_sgb_contract_wgrad(const float* gpool, const uint8_t* arg, const float* pooled, const float* a1, float* dw,
+                                  float* db, int64_t N, int64_t L, int64_t P, int32_t C, int32_t scale, float out_scale,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 /* Training forward of the SemiGlobalBlock's contracting path at sample_scale 80, split-fp16: relu(conv1) -> contract_conv ->
  * lrelu -> MaxPool1d(80) fused as in inference (models/stofnet.py:45,100-103; the [N, L, 512] activation never reaches HBM):
  * pooled[N][P][512] and arg[N][P][512] = row offset of each window's FIRST maximum (torch's max_pool1d backward routing).

@@ -800,6 +800,146 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// SemiGlobalBlock backward, contract_conv weight gradient from the pool's SPARSE gradient.  The gradient of
+// c = lrelu(contract_conv(a1)) behind MaxPool1d(S, S) is zero except at one time row per (waveform, window, channel)
+// -- 1 of S = 80 rows -- yet stof_train_pool_bwd + stof_train_wgrad build the dense [N, L, C] gradient (a 1-GB memset at
+// the benched shape) and run the dense weight-gradient kernel over it (0.59 ms of a 5.8 ms step).  Here a non-zero
+// (n, w, co) at row l* = w S + arg adds s a1[n][l* + d - 2][:] to dW[co][:][d], s = gpool * lrelu'(pooled):
+//   work-group = (block of 128 channels, share g of the (n, w) windows); it stages the window's S + 4 rows of a1 in LDS
+//   (the next window's rows are requested before the current one is used), wave k owns the 16 channels k, k + 8, ... of
+//   the block and keeps their 5 x 64 partial gradients in registers (lane = input channel): per non-zero five 256-byte
+//   LDS row reads and five FMAs.  One partial per work-group goes to the workspace; sgb_wgrad_reduce_kernel sums the G
+//   partials in a fixed order (bitwise reproducible, no float atomics) into the parameter's layout [C][64][5].
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int SGBW_CH = 128, SGBW_OWN = 16;                       // channels per work-group, per wave
+constexpr int SGBW_PIECES = 3, SGBW_ROWS = SGBW_PIECES * 512 / 16; // 16-byte pieces of a slab per thread; slab rows staged (>= S + 4)
+constexpr int SGBW_BUF_F = SGBW_ROWS * 64 + 3 * SGBW_CH;          // floats of one staging buffer: slab | gpool | pooled | arg (a dword each)
+constexpr int SGBW_NBUF = 3;
+struct SgbWgradParams {
+    const float* gpool;        // [N][P][C]
+    const unsigned char* arg;  // [N][P][C]
+    const float* pooled;       // [N][P][C]
+    const float* a1;           // [N][L][64]
+    float* part;               // [G][C][5][64]
+    float* dbpart;             // [G][C]
+    long long nwin;            // N * P
+    int L, P, C, S, G;
+};
+
+// s_waitcnt vmcnt(n), lgkmcnt(0) (gfx9 encoding; expcnt unconstrained)
+template <int n> __device__ __forceinline__ void wait_vm_lgkm0() { __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | ((n >> 4) << 14)); }
+
+// A work-group walks its windows q = g, g + G, ... with the inputs of the next two windows on their way: everything it
+// reads -- the S + 4 rows of a1, the 128 channels' gpool / pooled / arg -- is copied global -> LDS by global_load_lds
+// (no registers, no second pass through the vector pipe) into one of three buffers, retired by a counted vmcnt and one
+// raw barrier per window.  (An earlier form fetched the next window into registers one iteration ahead: 252 us -- each
+// window waited out a full memory round trip, ~5 us for ~1 us of work.)
+__global__ __launch_bounds__(512, 4) void sgb_contract_wgrad_kernel(const SgbWgradParams p) {      // (128 registers: two groups per CU)
+    extern __shared__ __attribute__((aligned(16))) float stage[];               // [SGBW_NBUF][SGBW_BUF_F]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = blockIdx.y, g = blockIdx.x, nf4 = (p.S + 4) * 16;
+    float acc[SGBW_OWN][5];
+#pragma unroll
+    for (int j = 0; j < SGBW_OWN; ++j)
+#pragma unroll
+        for (int d = 0; d < 5; ++d) acc[j][d] = 0.f;
+    float dbv = 0.f;                                             // lane j < 16: bias gradient of owned channel j
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    // every wave issues SGBW_PIECES slab pieces; waves 0-1 add gpool, 2-3 pooled, 4-5 arg (one instruction each)
+    auto issue = [&](long long q, int b) {
+        float* const buf = stage + (size_t)b * SGBW_BUF_F;
+        const long long n = q / p.P;
+        const int w = (int)(q - n * p.P);
+        const float* const src = p.a1 + n * (long long)p.L * 64;
+#pragma unroll
+        for (int k = 0; k < SGBW_PIECES; ++k) {
+            const int i = tid + 512 * k;
+            int l = w * p.S - 2 + (i >> 4);                       // rows outside the waveform: a valid address, zeroed after the copy
+            l = l < 0 ? 0 : (l > p.L - 1 ? p.L - 1 : l);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (long long)l * 64 + 4 * (i & 15)), (lptr_t)(buf + 4 * (i - lane)), 16, 0, 0);
+        }
+        const long long c0 = q * p.C + SGBW_CH * blk + 64 * (wave & 1);
+        float* const gp = buf + SGBW_ROWS * 64;
+        if (wave < 2) __builtin_amdgcn_global_load_lds((gptr_t)(p.gpool + c0 + lane), (lptr_t)(gp + 64 * (wave & 1)), 4, 0, 0);
+        else if (wave < 4) __builtin_amdgcn_global_load_lds((gptr_t)(p.pooled + c0 + lane), (lptr_t)(gp + SGBW_CH + 64 * (wave & 1)), 4, 0, 0);
+        else if (wave < 6)
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.arg + c0 + lane), (lptr_t)(gp + 2 * SGBW_CH + 64 * (wave & 1)), 1, 0, 0);
+        // (a sub-dword copy still lands one DWORD per lane, zero-extended)
+    };
+    long long q = g;
+    if (q < p.nwin) issue(q, 0);
+    if (q + p.G < p.nwin) issue(q + p.G, 1);
+    int b = 0;
+    for (; q < p.nwin; q += p.G) {
+        // this wave's copies of window q have landed (the next window's stay in flight); the barrier extends that to every
+        // wave's copies and says that everybody is done with the buffer the copies of window q + 2 G go to
+        if (q + p.G < p.nwin) { if (wave < 6) wait_vm_lgkm0<SGBW_PIECES + 1>(); else wait_vm_lgkm0<SGBW_PIECES>(); }
+        else wait_vm_lgkm0<0>();
+        __builtin_amdgcn_s_barrier();
+        if (q + 2ll * p.G < p.nwin) issue(q + 2ll * p.G, b == 0 ? 2 : b - 1);
+        float* const buf = stage + (size_t)b * SGBW_BUF_F;
+        const long long n = q / p.P;
+        const int w = (int)(q - n * p.P);
+        if (w == 0 || w * p.S + p.S + 2 > p.L) {                  // wave-uniform: rows before / behind the waveform are zero padding
+            for (int i = tid; i < nf4; i += 512) {
+                const int l = w * p.S - 2 + (i >> 4);
+                if (l < 0 || l >= p.L) *reinterpret_cast<float4*>(buf + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+        }
+        const float* const gp = buf + SGBW_ROWS * 64;
+        float s_cur = 0.f;
+        int p_cur = 0;
+        if (lane < SGBW_OWN) {
+            const int ch = wave + 8 * lane;
+            const float gv = gp[ch];
+            s_cur = gp[SGBW_CH + ch] > 0.f ? gv : 0.01f * gv;     // the activation at the arg-max IS the pooled value
+            p_cur = reinterpret_cast<const int*>(gp + 2 * SGBW_CH)[ch];
+        }
+        dbv += s_cur;
+#pragma unroll
+        for (int j = 0; j < SGBW_OWN; ++j) {
+            const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s_cur), j));      // wave-uniform
+            const int pj = __builtin_amdgcn_readlane(p_cur, j);
+            const float* row = buf + pj * 64 + lane;              // rows pj .. pj + 4 = l* - 2 .. l* + 2
+#pragma unroll
+            for (int d = 0; d < 5; ++d) acc[j][d] = fmaf(sj, row[64 * d], acc[j][d]);
+        }
+        b = b == SGBW_NBUF - 1 ? 0 : b + 1;
+    }
+    float* out = p.part + ((size_t)g * p.C + SGBW_CH * blk) * 320;
+#pragma unroll
+    for (int j = 0; j < SGBW_OWN; ++j)
+#pragma unroll
+        for (int d = 0; d < 5; ++d) out[(size_t)(wave + 8 * j) * 320 + 64 * d + lane] = acc[j][d];
+    if (lane < SGBW_OWN) p.dbpart[(size_t)g * p.C + SGBW_CH * blk + wave + 8 * lane] = dbv;
+}
+
+// dw[co][ci][d] = scale * sum_g part[g][co][d][ci],  db[co] = scale * sum_g dbpart[g][co]   (fixed order)
+__global__ __launch_bounds__(256) void sgb_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
+                                                               float* __restrict__ dw, float* __restrict__ db, int G, int C, float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                // (co, d, ci)
+    if (i < C * 320) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};                     // four interleaved chains (loads in flight), combined in a fixed order
+        int g = 0;
+        for (; g + 4 <= G; g += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += part[(size_t)(g + k) * C * 320 + i];
+        }
+        for (; g < G; ++g) a[0] += part[(size_t)g * C * 320 + i];
+        const int co = i / 320, r = i - co * 320, d = r >> 6, ci = r & 63;
+        dw[(size_t)co * 320 + ci * 5 + d] = ((a[0] + a[1]) + (a[2] + a[3])) * scale;
+    }
+    if (i < C) {
+        float b = 0.f;
+        for (int g = 0; g < G; ++g) b += dbpart[(size_t)g * C + i];
+        db[i] = b * scale;
+    }
+}
+
 // conv1 (1 -> 64, k9, pad 4) + ReLU, channel-last output; and its weight gradient
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y, int N, int L) {
@@ -1224,6 +1364,44 @@ extern "C" int stof_train_pool_bwd(const float* gpool, const uint8_t* arg, const
     if (N * P > 0)
         hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for(N * P * C)), dim3(256), 0, s, gpool, arg, c, c ? nullptr : pooled, gc, (int)N, (int)L,
                            (int)P, C, scale);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+// SemiGlobalBlock backward: contract_conv's weight / bias gradient straight from the pool's sparse gradient (see
+// sgb_contract_wgrad_kernel).  STOF_ERR_UNSUPPORTED for shapes it does not take (C not a multiple of 128, cin != 64,
+// S > 92): the caller then builds the dense gradient (stof_train_pool_bwd) and calls stof_train_wgrad.
+extern "C" size_t stof_train_sgb_wgrad_workspace_bytes(int32_t C) {
+    const int G = stof::device_cu_count() * 2 / (C / SGBW_CH > 0 ? C / SGBW_CH : 1);
+    return (size_t)(G > 0 ? G : 1) * C * 321 * sizeof(float);
+}
+
+extern "C" int stof_train_sgb_contract_wgrad(const float* gpool, const uint8_t* arg, const float* pooled, const float* a1, float* dw,
+                                             float* db, int64_t N, int64_t L, int64_t P, int32_t C, int32_t scale, float out_scale,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (N < 0 || L < 0 || P < 0 || C < 1 || scale < 1 || P * scale > L) return STOF_ERR_BAD_ARG;
+    if (C % SGBW_CH != 0 || scale + 4 > SGBW_ROWS || L > 0x7fffffff / 64) return STOF_ERR_UNSUPPORTED;
+    if (!dw || !db || !workspace) return STOF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int G = stof::device_cu_count() * 2 / (C / SGBW_CH);
+    if (G < 1) G = 1;
+    if (workspace_bytes < (size_t)G * C * 321 * sizeof(float)) return STOF_ERR_WORKSPACE;
+    if (N * P == 0) {
+        if (hipMemsetAsync(dw, 0, (size_t)C * 320 * sizeof(float), s) != hipSuccess ||
+            hipMemsetAsync(db, 0, (size_t)C * sizeof(float), s) != hipSuccess) return STOF_ERR_HIP;
+        return STOF_OK;
+    }
+    if (!gpool || !arg || !pooled || !a1) return STOF_ERR_BAD_ARG;
+    if (N * P < G) G = (int)(N * P);
+    SgbWgradParams p;
+    p.gpool = gpool; p.arg = arg; p.pooled = pooled; p.a1 = a1;
+    p.part = static_cast<float*>(workspace);
+    p.dbpart = p.part + (size_t)G * C * 320;
+    p.nwin = N * P; p.L = (int)L; p.P = (int)P; p.C = C; p.S = scale; p.G = G;
+    const size_t lds = (size_t)SGBW_NBUF * SGBW_BUF_F * sizeof(float);
+    static stof::LdsLimitOnce once;
+    if (int st = once.ensure(reinterpret_cast<const void*>(&sgb_contract_wgrad_kernel), 160 * 1024)) return st;
+    hipLaunchKernelGGL(sgb_contract_wgrad_kernel, dim3(G, C / SGBW_CH), dim3(512), lds, s, p);
+    hipLaunchKernelGGL(sgb_wgrad_reduce_kernel, dim3(blocks_for((long long)C * 320)), dim3(256), 0, s, p.part, p.dbpart, dw, db, G, C, out_scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

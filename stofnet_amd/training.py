@@ -49,6 +49,8 @@ class TrainEngine:
         self.sweep = (self.prec == 1 and (not self.sgb or self.scale == 80) and os.environ.get('STOF_TRAIN_SWEEP', '1') != '0'
                       and os.environ.get('STOF_BODY16', '1') != '0')
         self._sweep_blob = None
+        # SemiGlobalBlock backward from the pool's sparse gradient (STOF_TRAIN_SGB_SPARSE=0: dense route, for A/B runs and tests)
+        self.sparse_sgb = os.environ.get('STOF_TRAIN_SGB_SPARSE', '1') != '0'
         if self.sgb and not 2 <= self.scale <= 256:
             raise NotImplementedError('SemiGlobalBlock sample_scale must be in [2, 256] for the gfx950 kernels')
         self._gscale = 1.0
@@ -262,7 +264,21 @@ class TrainEngine:
             gc = torch.empty((n, L, cm), dtype=torch.float32, device=self.dev)
             _lib.check(lib.stof_train_pool_bwd(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(c), _lib.ptr(pooled), _lib.ptr(gc), n, L, P, cm, S, st),
                        'stof_train_pool_bwd')
-            self._wgrad(a1, gc, sg + 'contract_conv', 64, cm, 5)
+            # contract_conv's weight gradient from the pool's sparse gradient (one non-zero row per waveform, window and
+            # channel) where the kernel takes the shape; otherwise from the dense gc like every other layer
+            code = _lib.STOF_ERR_UNSUPPORTED
+            if self.sparse_sgb and pooled is not None:
+                need = lib.stof_train_sgb_wgrad_workspace_bytes(cm)
+                ws = getattr(self, '_sgb_wgrad_ws', None)
+                if ws is None or ws.numel() < need:
+                    ws = self._sgb_wgrad_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+                code = lib.stof_train_sgb_contract_wgrad(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(pooled), _lib.ptr(a1),
+                                                         _lib.ptr(g[sg + 'contract_conv.weight']), _lib.ptr(g[sg + 'contract_conv.bias']),
+                                                         n, L, P, cm, S, 1.0 / self._gscale, _lib.ptr(ws), ws.numel(), st)
+                if code != _lib.STOF_ERR_UNSUPPORTED:
+                    _lib.check(code, 'stof_train_sgb_contract_wgrad')
+            if code == _lib.STOF_ERR_UNSUPPORTED:
+                self._wgrad(a1, gc, sg + 'contract_conv', 64, cm, 5)
             g_a1 = self._conv(gc, bwd[sg + 'contract_conv'], None, cm, 64, 5, residual=g_x0)
         else:
             g_a1 = g_x0

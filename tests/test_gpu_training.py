@@ -62,6 +62,44 @@ def test_conv_kernels_vs_torch(dev, prec):
         assert relerr(t.g['w.weight'].cpu().numpy(), gw.numpy()) < 2e-6
         assert relerr(t.g['w.bias'].cpu().numpy(), gb.numpy()) < 2e-6
 
+@pytest.mark.parametrize('n,L,S,C', [(8, 2000, 80, 512), (1, 2000, 80, 512), (3, 1290, 40, 256), (2, 330, 20, 128)])
+def test_sgb_sparse_contract_weight_gradient_matches_dense_route(dev, n, L, S, C):
+    """stof_train_sgb_contract_wgrad (weight / bias gradient of contract_conv from the pool's sparse gradient) against the
+    dense route it replaces: stof_train_pool_bwd builds gc[N, L, C], stof_train_wgrad (exact fp32) reduces it; and against
+    a float64 einsum of the same sum.  Windows at both ends of the row (zero padding), a remainder behind the last window,
+    fewer windows than work-groups (n = 1)."""
+    from stofnet_amd import _lib
+    lib, st = _lib.lib(), _lib.stream_ptr(dev)
+    P = L // S
+    gen = torch.Generator(device='cpu').manual_seed(n * 1000 + L)
+    gpool = torch.randn(n, P, C, generator=gen).to(dev)
+    pooled = torch.randn(n, P, C, generator=gen).to(dev)
+    arg = torch.randint(0, S, (n, P, C), generator=gen, dtype=torch.int64).to(torch.uint8)
+    arg[:, 0, :C // 2] = 0                                   # first rows of the waveform: taps reach before it
+    arg[:, -1, C // 2:] = S - 1
+    arg = arg.to(dev)
+    a1 = torch.randn(n, L, 64, generator=gen).to(dev)
+    gc = torch.empty(n, L, C, device=dev)
+    _lib.check(lib.stof_train_pool_bwd(_lib.ptr(gpool), _lib.ptr(arg), None, _lib.ptr(pooled), _lib.ptr(gc), n, L, P, C, S, st), 'pool_bwd')
+    dw_ref, db_ref = torch.empty(C, 64, 5, device=dev), torch.empty(C, device=dev)
+    ws = torch.empty(lib.stof_train_wgrad_workspace_bytes(64, C, 5), dtype=torch.uint8, device=dev)
+    _lib.check(lib.stof_train_wgrad(_lib.ptr(a1), _lib.ptr(gc), _lib.ptr(dw_ref), _lib.ptr(db_ref), n, L, 64, C, 5, 0.25, 0, _lib.ptr(ws),
+                                    ws.numel(), st), 'wgrad')
+    dw, db = torch.empty(C, 64, 5, device=dev), torch.empty(C, device=dev)
+    ws2 = torch.empty(lib.stof_train_sgb_wgrad_workspace_bytes(C), dtype=torch.uint8, device=dev)
+    _lib.check(lib.stof_train_sgb_contract_wgrad(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(pooled), _lib.ptr(a1), _lib.ptr(dw), _lib.ptr(db),
+                                                 n, L, P, C, S, 0.25, _lib.ptr(ws2), ws2.numel(), st), 'sgb_contract_wgrad')
+    torch.cuda.synchronize()
+    pad = torch.nn.functional.pad(a1.double().cpu(), (0, 0, 2, 2))
+    exact = 0.25 * torch.stack([torch.einsum('nlo,nlc->oc', gc.double().cpu(), pad[:, d:d + L]) for d in range(5)], dim=2)
+    assert relerr(dw.cpu().numpy(), exact.numpy()) < 2e-6 and relerr(dw_ref.cpu().numpy(), exact.numpy()) < 2e-6
+    assert relerr(db.cpu().numpy(), 0.25 * gc.double().sum((0, 1)).cpu().numpy()) < 2e-6
+    assert relerr(dw.cpu().numpy(), dw_ref.cpu().numpy()) < 2e-6 and relerr(db.cpu().numpy(), db_ref.cpu().numpy()) < 2e-6
+    # shapes the kernel does not take are reported, not computed wrongly
+    assert lib.stof_train_sgb_contract_wgrad(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(pooled), _lib.ptr(a1), _lib.ptr(dw), _lib.ptr(db),
+                                             n, L, P, 64, S, 1.0, _lib.ptr(ws2), ws2.numel(), st) == _lib.STOF_ERR_UNSUPPORTED
+
+
 
 @pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
 @pytest.mark.parametrize('r,sgs,L', [(4, 80, 400), (10, 80, 336), (4, 1, 250)])
