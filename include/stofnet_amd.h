@@ -311,6 +311,14 @@ int stof_train_pool_bwd(const float* gpool, const uint8_t* arg, const float* c, 
  * stof_train_wgrad(a1, gc, cin 64, cout C, K 5) produce, without the dense [N, L, C] tensor.  gpool / arg / pooled[N, P, C]
  * as for stof_train_pool_bwd, a1[N, L, 64] the convolution's input.  STOF_ERR_UNSUPPORTED when C is not a multiple of 128
  * or scale > 92 (the caller then takes the dense route).                                                            */
+/* ... and its data gradient: out[N, L, 64] = resid (may be NULL) + conv_transpose(gc, weight[C][64][5]) = what
+ * stof_train_pool_bwd + the data-gradient stof_train_conv produce, from the same sparse inputs, in a fixed summation
+ * order.  workspace: stof_train_sgb_dgrad_workspace_bytes(C) bytes.  STOF_ERR_UNSUPPORTED when C is not a multiple of 64,
+ * C > 512, scale > 88, scale < 4 or P == 0.                                                                          */
+size_t stof_train_sgb_dgrad_workspace_bytes(int32_t C);
+int stof_train_sgb_contract_dgrad(const float* gpool, const uint8_t* arg, const float* pooled, const float* weight,
+                                  const float* resid, float* out, int64_t N, int64_t L, int64_t P, int32_t C, int32_t scale,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 size_t stof_train_sgb_wgrad_workspace_bytes(int32_t C);
 int stof_train_sgb_contract_wgrad(const float* gpool, const uint8_t* arg, const float* pooled, const float* a1, float* dw,
                                   float* db, int64_t N, int64_t L, int64_t P, int32_t C, int32_t scale, float out_scale,

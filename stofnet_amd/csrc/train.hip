@@ -918,6 +918,177 @@ __global__ __launch_bounds__(512, 4) void sgb_contract_wgrad_kernel(const SgbWgr
     if (lane < SGBW_OWN) p.dbpart[(size_t)g * p.C + SGBW_CH * blk + wave + 8 * lane] = dbv;
 }
 
+// orders a wave's LDS accesses for the compiler (the hardware executes one wave's LDS instructions in order)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// SemiGlobalBlock backward, contract_conv data gradient from the same sparse gradient: a non-zero (n, w, co) at row
+// l* = w S + arg adds s W[co][:][d] to dL/da1[n][l* + d - 2][:] for the five taps.  One WAVE per window (n, w), lane = input
+// channel quad x list-entry quarter, no atomics and a fixed summation order:
+//   * the wave sets a bit per (position, channel) in an LDS bit matrix for its window and for the two positions of each
+//     neighbouring window that reach its rows;
+//   * it walks the positions in order with FIVE accumulators in registers -- the rows a position reaches: after position
+//     pi the oldest row is complete, is stored, and the accumulators shift (the incoming one starts from the residual
+//     the dense convolution would have added, fetched a few rows ahead);
+//   * the channels of a position come out of the bit matrix as a list (rank by mbcnt); eight at a time, their five
+//     256-byte weight rows (L2-resident 655-KB table wt[co][d][ci]) and their s values are requested together: 16-byte
+//     loads, a quarter of the wave per list entry, so one instruction fetches four rows.
+// Replaces a 1-GB memset, stof_train_pool_bwd and a 503-GFLOP dense convolution over 98.75 % zeros (0.83 ms of a step).
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int SGBD_WAVES = 4, SGBD_MAXC = 512, SGBD_MAXS = 88, SGBD_GROUP = 2;      // (28 KB of LDS per work-group: five per CU; 4 x GROUP list entries per step)
+constexpr int SGBD_PI = SGBD_MAXS + 6;                           // positions pi = rel + 2, rel = -2 .. S + 3 (the last two only flush)
+struct SgbDgradParams {
+    const float* gpool;        // [N][P][C]
+    const unsigned char* arg;  // [N][P][C]
+    const float* pooled;       // [N][P][C]
+    const float* wt;           // [C][5][64] = contract_conv.weight[co][ci][d] transposed
+    const float* resid;        // [N][L][64] or nullptr
+    float* out;                // [N][L][64]
+    long long nwin;            // N * P
+    int L, P, C, S;
+};
+
+__global__ __launch_bounds__(64 * SGBD_WAVES) void sgb_contract_dgrad_kernel(const SgbDgradParams p) {
+    __shared__ unsigned long long pm_all[SGBD_WAVES][SGBD_PI][SGBD_MAXC / 64];
+    __shared__ unsigned short list_all[SGBD_WAVES][2][SGBD_MAXC];          // (two lists: the next position's is built under this one's loads)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long q = (long long)blockIdx.x * SGBD_WAVES + wave;
+    if (q >= p.nwin) return;                                     // (no work-group barrier below: a wave is on its own)
+    unsigned long long (*pm)[SGBD_MAXC / 64] = pm_all[wave];
+    const int S = p.S, L = p.L, C = p.C, NW = C / 64;
+    const long long n = q / p.P;
+    const int w = (int)(q - n * p.P);
+    const bool last = w == p.P - 1;
+    const int npi = S + 6;                                        // positions walked
+    for (int i = lane; i < npi * (SGBD_MAXC / 64); i += 64) (&pm[0][0])[i] = 0ull;
+    wave_lds_fence();
+    // bits of the previous / this / next window (positions rel = arg + (t - 1) S; kept: -2 <= rel < S + 2); all the
+    // arg-max bytes are requested before the first one is used
+    {
+        int av[3][SGBD_MAXC / 64];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int wn = w + t - 1, wc = wn < 0 ? 0 : (wn >= p.P ? p.P - 1 : wn);
+            const unsigned char* src = p.arg + (n * p.P + wc) * (long long)C + lane;
+#pragma unroll
+            for (int k = 0; k < SGBD_MAXC / 64; ++k) av[t][k] = (k < NW) ? (int)src[64 * k] : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int wn = w + t - 1;
+#pragma unroll
+            for (int k = 0; k < SGBD_MAXC / 64; ++k) {
+                const int pi = av[t][k] + (t - 1) * S + 2;
+                if (k < NW && wn >= 0 && wn < p.P && pi >= 0 && pi < S + 4) atomicOr(&pm[pi][k], 1ull << lane);
+            }
+        }
+    }
+    wave_lds_fence();
+    // rows: r = l - w S; accumulator d at step pi holds row r = pi + d - 4.  Owned rows: 0 .. S - 1 (the last window also
+    // takes the rows behind it).  Lane = (quarter sub = lane >> 4, channels 4 c4 .. 4 c4 + 3, c4 = lane & 15): a 16-byte
+    // load per lane fetches FOUR weight rows per instruction, one per quarter (the texture addresser takes a wave's 64
+    // addresses at the same pace whatever their width: dword loads, one row per instruction, made it the bottleneck at
+    // 0.65 ms); quarter `sub` accumulates the list entries e = sub mod 4 and the quarters are added when a row is complete.
+    const float* const resid = p.resid ? p.resid + n * (long long)L * 64 : nullptr;
+    float* const dst = p.out + n * (long long)L * 64;
+    const int l0 = w * S, r_end = last ? L - l0 : S, sub = lane >> 4, c4 = lane & 15;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto initial = [&](int r) -> float4 {                        // the residual, on quarter 0
+        const int l = l0 + r;
+        return (resid && sub == 0 && r >= 0 && l < L) ? *reinterpret_cast<const float4*>(resid + (long long)l * 64 + 4 * c4) : zero4;
+    };
+    constexpr int AHEAD = 4;
+    float4 acc[5], nxt[AHEAD];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) acc[d] = initial(d - 4);
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) nxt[a] = initial(1 + a);    // rows entering at the steps pi = 0 .. AHEAD - 1
+    // the channels of position pi, ascending, into list buffer pi & 1; returns their number.  Lane k holds word k of the
+    // position's bit row (one LDS read), the words reach the scalar side by readlane.
+    auto build_list = [&](int pi) -> int {
+        unsigned short* const list = list_all[wave][pi & 1];
+        const unsigned long long mine = lane < NW ? pm[pi][lane] : 0ull;
+        int count = 0;
+#pragma unroll
+        for (int k = 0; k < SGBD_MAXC / 64; ++k) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, k);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), k);
+            if ((lo | hi) == 0u) continue;
+            const unsigned long long word = ((unsigned long long)hi << 32) | lo;
+            const int rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
+            if ((word >> lane) & 1ull) list[count + rank] = (unsigned short)(64 * k + lane);
+            count += __builtin_popcount(lo) + __builtin_popcount(hi);
+        }
+        return count;
+    };
+    int count = build_list(0);
+    wave_lds_fence();
+    for (int pi = 0; pi < npi; ++pi) {
+        const int t = pi < 2 ? 0 : (pi < S + 2 ? 1 : 2);
+        const unsigned short* const list = list_all[wave][pi & 1];
+        int count_next = 0;
+        // s = gpool * lrelu'(pooled) is read with the weight rows (keeping three windows' values in LDS would halve the waves
+        // per CU)
+        const int wn = w + t - 1;                                // (a neighbour that does not exist has no bits; its loads stay in range)
+        const long long sbase = (n * p.P + (wn < 0 ? 0 : (wn >= p.P ? p.P - 1 : wn))) * (long long)C;
+        for (int e0 = 0; e0 < count || e0 == 0; e0 += 4 * SGBD_GROUP) {
+            float gx[SGBD_GROUP], px[SGBD_GROUP];
+            float4 wv[SGBD_GROUP][5];
+#pragma unroll
+            for (int u = 0; u < SGBD_GROUP; ++u) {
+                const int e = e0 + 4 * u + sub;
+                const int co = e < count ? (int)list[e] : 0;      // (an entry past the list reads channel 0 and counts for nothing)
+                gx[u] = p.gpool[sbase + co];
+                px[u] = p.pooled[sbase + co];
+                const float* wr = p.wt + (size_t)co * 320 + 4 * c4;
+#pragma unroll
+                for (int d = 0; d < 5; ++d) wv[u][d] = *reinterpret_cast<const float4*>(wr + 64 * d);
+            }
+            if (e0 == 0 && pi + 1 < npi) count_next = build_list(pi + 1);       // under the loads just issued
+#pragma unroll
+            for (int u = 0; u < SGBD_GROUP; ++u) {
+                const float sv = px[u] > 0.f ? gx[u] : 0.01f * gx[u];     // the activation at the arg-max IS the pooled value
+                const float sx = (e0 + 4 * u + sub < count) ? sv : 0.f;
+#pragma unroll
+                for (int d = 0; d < 5; ++d) {
+                    acc[d].x = fmaf(sx, wv[u][d].x, acc[d].x); acc[d].y = fmaf(sx, wv[u][d].y, acc[d].y);
+                    acc[d].z = fmaf(sx, wv[u][d].z, acc[d].z); acc[d].w = fmaf(sx, wv[u][d].w, acc[d].w);
+                }
+            }
+        }
+        count = count_next;
+        wave_lds_fence();                                        // the next position's list is complete
+        const int r = pi - 4;
+        if (r >= 0 && r < r_end && r < S + 2) {                    // wave-uniform: the row is complete -- add the quarters, store
+            float4 v = acc[0];
+            v.x += __shfl_xor(v.x, 16); v.y += __shfl_xor(v.y, 16); v.z += __shfl_xor(v.z, 16); v.w += __shfl_xor(v.w, 16);
+            v.x += __shfl_xor(v.x, 32); v.y += __shfl_xor(v.y, 32); v.z += __shfl_xor(v.z, 32); v.w += __shfl_xor(v.w, 32);
+            if (sub == 0) *reinterpret_cast<float4*>(dst + (long long)(l0 + r) * 64 + 4 * c4) = v;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[d] = acc[d + 1];
+        acc[4] = nxt[0];
+#pragma unroll
+        for (int a = 0; a + 1 < AHEAD; ++a) nxt[a] = nxt[a + 1];
+        nxt[AHEAD - 1] = initial(pi + 1 + AHEAD);
+    }
+    // the last window: rows no position reaches keep the residual
+    if (last && sub == 0)
+        for (int r = S + 2; r < r_end; ++r) *reinterpret_cast<float4*>(dst + (long long)(l0 + r) * 64 + 4 * c4) = initial(r);
+}
+
+// wt[co][d][ci] = w[co][ci][d]
+__global__ __launch_bounds__(256) void sgb_wt_repack_kernel(const float* __restrict__ w, float* __restrict__ wt, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * 320) return;
+    const int co = i / 320, r = i - co * 320, d = r >> 6, ci = r & 63;
+    wt[i] = w[(size_t)co * 320 + ci * 5 + d];
+}
+
 // dw[co][ci][d] = scale * sum_g part[g][co][d][ci],  db[co] = scale * sum_g dbpart[g][co]   (fixed order)
 __global__ __launch_bounds__(256) void sgb_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                                float* __restrict__ dw, float* __restrict__ db, int G, int C, float scale) {
@@ -1402,6 +1573,31 @@ extern "C" int stof_train_sgb_contract_wgrad(const float* gpool, const uint8_t* 
     if (int st = once.ensure(reinterpret_cast<const void*>(&sgb_contract_wgrad_kernel), 160 * 1024)) return st;
     hipLaunchKernelGGL(sgb_contract_wgrad_kernel, dim3(G, C / SGBW_CH), dim3(512), lds, s, p);
     hipLaunchKernelGGL(sgb_wgrad_reduce_kernel, dim3(blocks_for((long long)C * 320)), dim3(256), 0, s, p.part, p.dbpart, dw, db, G, C, out_scale);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+// SemiGlobalBlock backward: dL/da1 = resid (may be NULL) + conv_transpose(gc, contract_conv.weight) from the pool's sparse
+// gradient (see sgb_contract_dgrad_kernel); out[N, L, 64], fixed summation order.  workspace: C * 320 floats (the weights
+// transposed).  STOF_ERR_UNSUPPORTED when C is not a multiple of 64, C > 512, scale > 88, scale < 4 or P == 0 (the caller then
+// takes the dense route).
+extern "C" size_t stof_train_sgb_dgrad_workspace_bytes(int32_t C) { return (size_t)(C > 0 ? C : 0) * 320 * sizeof(float); }
+
+extern "C" int stof_train_sgb_contract_dgrad(const float* gpool, const uint8_t* arg, const float* pooled, const float* weight,
+                                             const float* resid, float* out, int64_t N, int64_t L, int64_t P, int32_t C, int32_t scale,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (N < 0 || L < 0 || P < 0 || C < 1 || scale < 1 || P * scale > L) return STOF_ERR_BAD_ARG;
+    if (C % 64 != 0 || C > SGBD_MAXC || scale > SGBD_MAXS || scale < 4 || P == 0 || L > 0x7fffffff / 64 || N * P > 0x7fffffffLL)
+        return STOF_ERR_UNSUPPORTED;
+    if (N == 0) return STOF_OK;
+    if (!out || !weight || !gpool || !arg || !pooled || !workspace) return STOF_ERR_BAD_ARG;
+    if (workspace_bytes < stof_train_sgb_dgrad_workspace_bytes(C)) return STOF_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* const wt = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(sgb_wt_repack_kernel, dim3(blocks_for((long long)C * 320)), dim3(256), 0, s, weight, wt, C);
+    SgbDgradParams p;
+    p.gpool = gpool; p.arg = arg; p.pooled = pooled; p.wt = wt; p.resid = resid; p.out = out;
+    p.nwin = N * P; p.L = (int)L; p.P = (int)P; p.C = C; p.S = scale;
+    hipLaunchKernelGGL(sgb_contract_dgrad_kernel, dim3((unsigned)((N * P + SGBD_WAVES - 1) / SGBD_WAVES)), dim3(64 * SGBD_WAVES), 0, s, p);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

@@ -51,6 +51,7 @@ class TrainEngine:
         self._sweep_blob = None
         # SemiGlobalBlock backward from the pool's sparse gradient (STOF_TRAIN_SGB_SPARSE=0: dense route, for A/B runs and tests)
         self.sparse_sgb = os.environ.get('STOF_TRAIN_SGB_SPARSE', '1') != '0'
+        self.sparse_sgb_dgrad = os.environ.get('STOF_TRAIN_SGB_SPARSE_DGRAD', '1') != '0'
         if self.sgb and not 2 <= self.scale <= 256:
             raise NotImplementedError('SemiGlobalBlock sample_scale must be in [2, 256] for the gfx950 kernels')
         self._gscale = 1.0
@@ -160,7 +161,8 @@ class TrainEngine:
             xs = [t[0]] + [t[2 + 2 * k] for k in range(5)]
             ys = [t[1 + 2 * k] for k in range(5)]
             saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=t[11], bwd=bwd, n=n, L=L, P=P, rem=rem,
-                         _dump=dump, desc=desc, wdev=[p[f'conv{i}.weight'] for i in range(2, 13)])
+                         _dump=dump, desc=desc, wdev=[p[f'conv{i}.weight'] for i in range(2, 13)],
+                         wc=p.get(sg + 'contract_conv.weight'))
             return z, saved
         if self.sgb:
             x0, c, pooled, arg, e = self._sgb_forward(a1, fwd[sg + 'contract_conv'], p[sg + 'contract_conv.bias'],
@@ -182,7 +184,8 @@ class TrainEngine:
         z = self._conv(x6, fwd['conv_last'], p['conv_last.bias'], 64, r, 3, ACT_NONE)      # [N, L, r] == shuffled [N, L*r]
         if not keep:
             return z.view(n, L * r), None
-        saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=x6, bwd=bwd, n=n, L=L, P=P, rem=rem)
+        saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=x6, bwd=bwd, n=n, L=L, P=P, rem=rem,
+                     wc=p.get('semi_global_block.contract_conv.weight'))
         return z.view(n, L * r), saved
 
     def _sgb_head(self, a1, w_contract, b_contract, w_expand, b_expand):
@@ -261,25 +264,41 @@ class TrainEngine:
                        'stof_train_upsample_bwd')
             self._wgrad(pooled, ge, sg + 'expand_conv', cm, 64, 5)
             gpool = self._conv(ge, bwd[sg + 'expand_conv'], None, 64, cm, 5)
-            gc = torch.empty((n, L, cm), dtype=torch.float32, device=self.dev)
-            _lib.check(lib.stof_train_pool_bwd(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(c), _lib.ptr(pooled), _lib.ptr(gc), n, L, P, cm, S, st),
-                       'stof_train_pool_bwd')
-            # contract_conv's weight gradient from the pool's sparse gradient (one non-zero row per waveform, window and
-            # channel) where the kernel takes the shape; otherwise from the dense gc like every other layer
-            code = _lib.STOF_ERR_UNSUPPORTED
-            if self.sparse_sgb and pooled is not None:
-                need = lib.stof_train_sgb_wgrad_workspace_bytes(cm)
-                ws = getattr(self, '_sgb_wgrad_ws', None)
-                if ws is None or ws.numel() < need:
-                    ws = self._sgb_wgrad_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
-                code = lib.stof_train_sgb_contract_wgrad(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(pooled), _lib.ptr(a1),
-                                                         _lib.ptr(g[sg + 'contract_conv.weight']), _lib.ptr(g[sg + 'contract_conv.bias']),
-                                                         n, L, P, cm, S, 1.0 / self._gscale, _lib.ptr(ws), ws.numel(), st)
-                if code != _lib.STOF_ERR_UNSUPPORTED:
-                    _lib.check(code, 'stof_train_sgb_contract_wgrad')
-            if code == _lib.STOF_ERR_UNSUPPORTED:
-                self._wgrad(a1, gc, sg + 'contract_conv', 64, cm, 5)
-            g_a1 = self._conv(gc, bwd[sg + 'contract_conv'], None, cm, 64, 5, residual=g_x0)
+            # The gradient behind the max-pool is zero except at ONE row per (waveform, window, channel).  Where the kernels
+            # take the shape, contract_conv's weight gradient and data gradient come straight from those non-zeros
+            # (stof_train_sgb_contract_wgrad / _dgrad); otherwise -- and with STOF_TRAIN_SGB_SPARSE=0 -- the dense [N, L, cm]
+            # gradient is built (stof_train_pool_bwd) and goes through the layer kernels like every other convolution.
+            U = _lib.STOF_ERR_UNSUPPORTED
+            wcode = dcode = U
+            g_a1 = None
+            if self.sparse_sgb and pooled is not None and saved.get('wc') is not None:
+                def scratch(name, need):
+                    ws = getattr(self, name, None)
+                    if ws is None or ws.numel() < need:
+                        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.dev)
+                        setattr(self, name, ws)
+                    return ws
+                ws = scratch('_sgb_wgrad_ws', lib.stof_train_sgb_wgrad_workspace_bytes(cm))
+                wcode = lib.stof_train_sgb_contract_wgrad(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(pooled), _lib.ptr(a1),
+                                                          _lib.ptr(g[sg + 'contract_conv.weight']), _lib.ptr(g[sg + 'contract_conv.bias']),
+                                                          n, L, P, cm, S, 1.0 / self._gscale, _lib.ptr(ws), ws.numel(), st)
+                if wcode != U:
+                    _lib.check(wcode, 'stof_train_sgb_contract_wgrad')
+                if self.sparse_sgb_dgrad:
+                    ws = scratch('_sgb_dgrad_ws', lib.stof_train_sgb_dgrad_workspace_bytes(cm))
+                    g_a1 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
+                    dcode = lib.stof_train_sgb_contract_dgrad(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(pooled), _lib.ptr(saved['wc'].contiguous()),
+                                                              _lib.ptr(g_x0), _lib.ptr(g_a1), n, L, P, cm, S, _lib.ptr(ws), ws.numel(), st)
+                    if dcode != U:
+                        _lib.check(dcode, 'stof_train_sgb_contract_dgrad')
+            if wcode == U or dcode == U:
+                gc = torch.empty((n, L, cm), dtype=torch.float32, device=self.dev)
+                _lib.check(lib.stof_train_pool_bwd(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(c), _lib.ptr(pooled), _lib.ptr(gc), n, L, P, cm, S, st),
+                           'stof_train_pool_bwd')
+                if wcode == U:
+                    self._wgrad(a1, gc, sg + 'contract_conv', 64, cm, 5)
+                if dcode == U:
+                    g_a1 = self._conv(gc, bwd[sg + 'contract_conv'], None, cm, 64, 5, residual=g_x0)
         else:
             g_a1 = g_x0
         ws1 = torch.empty(lib.stof_train_conv1_wgrad_workspace_bytes(), dtype=torch.uint8, device=self.dev)

@@ -95,6 +95,25 @@ def test_sgb_sparse_contract_weight_gradient_matches_dense_route(dev, n, L, S, C
     assert relerr(dw.cpu().numpy(), exact.numpy()) < 2e-6 and relerr(dw_ref.cpu().numpy(), exact.numpy()) < 2e-6
     assert relerr(db.cpu().numpy(), 0.25 * gc.double().sum((0, 1)).cpu().numpy()) < 2e-6
     assert relerr(dw.cpu().numpy(), dw_ref.cpu().numpy()) < 2e-6 and relerr(db.cpu().numpy(), db_ref.cpu().numpy()) < 2e-6
+    # the data gradient from the same non-zeros: resid + conv_transpose(gc, w), bitwise repeatable
+    w = torch.randn(C, 64, 5, generator=gen).to(dev)
+    resid = torch.randn(n, L, 64, generator=gen).to(dev)
+    out = torch.empty(n, L, 64, device=dev)
+    ws3 = torch.empty(lib.stof_train_sgb_dgrad_workspace_bytes(C), dtype=torch.uint8, device=dev)
+    ref = torch.nn.functional.conv_transpose1d(gc.double().cpu().permute(0, 2, 1), w.double().cpu(), padding=2).permute(0, 2, 1)
+    for r_ in (resid, None):
+        out.fill_(float('nan'))
+        _lib.check(lib.stof_train_sgb_contract_dgrad(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(pooled), _lib.ptr(w), _lib.ptr(r_), _lib.ptr(out),
+                                                     n, L, P, C, S, _lib.ptr(ws3), ws3.numel(), st), 'sgb_contract_dgrad')
+        torch.cuda.synchronize()
+        exp = ref + resid.double().cpu() if r_ is not None else ref
+        assert relerr(out.cpu().numpy(), exp.numpy()) < 2e-6
+    again = torch.empty_like(out)
+    _lib.check(lib.stof_train_sgb_contract_dgrad(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(pooled), _lib.ptr(w), None, _lib.ptr(again),
+                                                 n, L, P, C, S, _lib.ptr(ws3), ws3.numel(), st), 'sgb_contract_dgrad')
+    assert torch.equal(out, again)
+    assert lib.stof_train_sgb_contract_dgrad(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(pooled), _lib.ptr(w), None, _lib.ptr(again),
+                                             n, L, P, C, 100, _lib.ptr(ws3), ws3.numel(), st) in (_lib.STOF_ERR_UNSUPPORTED, _lib.STOF_ERR_BAD_ARG)
     # shapes the kernel does not take are reported, not computed wrongly
     assert lib.stof_train_sgb_contract_wgrad(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(pooled), _lib.ptr(a1), _lib.ptr(dw), _lib.ptr(db),
                                              n, L, P, 64, S, 1.0, _lib.ptr(ws2), ws2.numel(), st) == _lib.STOF_ERR_UNSUPPORTED
