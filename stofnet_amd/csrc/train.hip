@@ -1007,23 +1007,27 @@ __global__ __launch_bounds__(64 * SGBD_WAVES) void sgb_contract_dgrad_kernel(con
     for (int d = 0; d < 5; ++d) acc[d] = initial(d - 4);
 #pragma unroll
     for (int a = 0; a < AHEAD; ++a) nxt[a] = initial(1 + a);    // rows entering at the steps pi = 0 .. AHEAD - 1
-    // the channels of position pi, ascending, into list buffer pi & 1; returns their number.  Lane k holds word k of the
-    // position's bit row (one LDS read), the words reach the scalar side by readlane.
+    // the channels of position pi, ascending, into list buffer pi & 1; returns their number.  Lane l takes byte l of the
+    // position's 512-bit row (channels 8 l .. 8 l + 7): an exclusive scan of the bytes' bit counts over the wave gives each
+    // lane its place in the list, and a lane writes its own (rarely more than one) channels.  (A form that walked the row's
+    // eight 64-bit words with readlane / mbcnt cost ~160 vector instructions per position, a quarter of the kernel.)
     auto build_list = [&](int pi) -> int {
         unsigned short* const list = list_all[wave][pi & 1];
-        const unsigned long long mine = lane < NW ? pm[pi][lane] : 0ull;
-        int count = 0;
+        unsigned bits = lane < 8 * NW ? (unsigned)reinterpret_cast<const unsigned char*>(&pm[pi][0])[lane] : 0u;
+        const int mine = __builtin_popcount(bits);
+        int incl = mine;                                          // inclusive scan over the 64 lanes
 #pragma unroll
-        for (int k = 0; k < SGBD_MAXC / 64; ++k) {
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, k);
-            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), k);
-            if ((lo | hi) == 0u) continue;
-            const unsigned long long word = ((unsigned long long)hi << 32) | lo;
-            const int rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
-            if ((word >> lane) & 1ull) list[count + rank] = (unsigned short)(64 * k + lane);
-            count += __builtin_popcount(lo) + __builtin_popcount(hi);
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
         }
-        return count;
+        int at = incl - mine;
+        while (bits) {                                            // (divergent: as many rounds as the fullest byte has channels)
+            const int b = __builtin_ctz(bits);
+            bits &= bits - 1u;
+            list[at++] = (unsigned short)(8 * lane + b);
+        }
+        return __builtin_amdgcn_readlane(incl, 63);
     };
     int count = build_list(0);
     wave_lds_fence();
