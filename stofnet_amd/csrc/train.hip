@@ -770,28 +770,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradPar
 
 // dw[o][c][d] = sum_g part[g][d][o][c];  db[o] = sum_g dbpart[g][o]   (fixed summation order).
 // One work-group: 64 consecutive elements x 4 interleaved slices of g, combined through LDS.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
-                                                           float* __restrict__ dw, float* __restrict__ db, int G, int K,
-                                                           int cout, int cin, int cout_pad, int cin_pad, float out_scale) {
-    __shared__ float red[4][64];
+constexpr int WRED_SLICES = 16;                                   // interleaved slices of g per work-group (one wave each)
+__global__ __launch_bounds__(64 * WRED_SLICES) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
+                                                                        float* __restrict__ dw, float* __restrict__ db, int G, int K,
+                                                                        int cout, int cin, int cout_pad, int cin_pad, float out_scale) {
+    __shared__ float red[WRED_SLICES][64];
     const int per = K * cout_pad * cin_pad;
     const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + e;
-    float s0 = 0.f, s1 = 0.f;
+    // The launch has only ~450 work-groups of 64 elements: with four waves each and two loads per wave in flight the 58 MB
+    // of partials of a layer came in at 1.8 TB/s (32 us).  Sixteen waves per group, four chains each: 16 x more on its way.
+    // Slices and chains are combined in a fixed order.
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
     if (i < per) {
         int g = gq;
-        for (; g + 4 < G; g += 8) {
-            s0 += part[(size_t)g * per + i];
-            s1 += part[(size_t)(g + 4) * per + i];
+        for (; g + 3 * WRED_SLICES < G; g += 4 * WRED_SLICES) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += part[(size_t)(g + WRED_SLICES * k) * per + i];
         }
-        if (g < G) s0 += part[(size_t)g * per + i];
+        for (; g < G; g += WRED_SLICES) a[0] += part[(size_t)g * per + i];
     } else if (i - per < cout_pad) {
-        for (int g = gq; g < G; g += 4) s0 += dbpart[(size_t)g * cout_pad + (i - per)];
+        for (int g = gq; g < G; g += WRED_SLICES) a[0] += dbpart[(size_t)g * cout_pad + (i - per)];
     }
-    red[gq][e] = s0 + s1;
+    red[gq][e] = (a[0] + a[1]) + (a[2] + a[3]);
     __syncthreads();
     if (gq != 0) return;
-    const float s = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * out_scale;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < WRED_SLICES; q += 4) s += (red[q][e] + red[q + 1][e]) + (red[q + 2][e] + red[q + 3][e]);
+    s *= out_scale;
     if (i < per) {
         const int c = i % cin_pad, o = (i / cin_pad) % cout_pad, d = i / (cin_pad * cout_pad);
         if (o < cout && c < cin) dw[((size_t)o * cin + c) * K + d] = s;
@@ -1093,25 +1100,36 @@ __global__ __launch_bounds__(256) void sgb_wt_repack_kernel(const float* __restr
     wt[i] = w[(size_t)co * 320 + ci * 5 + d];
 }
 
-// dw[co][ci][d] = scale * sum_g part[g][co][d][ci],  db[co] = scale * sum_g dbpart[g][co]   (fixed order)
-__global__ __launch_bounds__(256) void sgb_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
-                                                               float* __restrict__ dw, float* __restrict__ db, int G, int C, float scale) {
-    const int i = blockIdx.x * 256 + threadIdx.x;                // (co, d, ci)
-    if (i < C * 320) {
-        float a[4] = {0.f, 0.f, 0.f, 0.f};                     // four interleaved chains (loads in flight), combined in a fixed order
-        int g = 0;
-        for (; g + 4 <= G; g += 4) {
+// dw[co][ci][d] = scale * sum_g part[g][co][d][ci],  db[co] = scale * sum_g dbpart[g][co]   (fixed order; sixteen interleaved
+// slices of g per work-group as in wgrad_reduce_kernel, for the loads in flight)
+__global__ __launch_bounds__(64 * WRED_SLICES) void sgb_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
+                                                                            float* __restrict__ dw, float* __restrict__ db, int G, int C, float scale) {
+    __shared__ float red[WRED_SLICES][64];
+    const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + e, per = C * 320;            // i < per: (co, d, ci); then the C bias entries
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < per) {
+        int g = gq;
+        for (; g + 3 * WRED_SLICES < G; g += 4 * WRED_SLICES) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] += part[(size_t)(g + k) * C * 320 + i];
+            for (int k = 0; k < 4; ++k) a[k] += part[(size_t)(g + WRED_SLICES * k) * per + i];
         }
-        for (; g < G; ++g) a[0] += part[(size_t)g * C * 320 + i];
-        const int co = i / 320, r = i - co * 320, d = r >> 6, ci = r & 63;
-        dw[(size_t)co * 320 + ci * 5 + d] = ((a[0] + a[1]) + (a[2] + a[3])) * scale;
+        for (; g < G; g += WRED_SLICES) a[0] += part[(size_t)g * per + i];
+    } else if (i - per < C) {
+        for (int g = gq; g < G; g += WRED_SLICES) a[0] += dbpart[(size_t)g * C + (i - per)];
     }
-    if (i < C) {
-        float b = 0.f;
-        for (int g = 0; g < G; ++g) b += dbpart[(size_t)g * C + i];
-        db[i] = b * scale;
+    red[gq][e] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (gq != 0) return;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < WRED_SLICES; q += 4) s += (red[q][e] + red[q + 1][e]) + (red[q + 2][e] + red[q + 3][e]);
+    s *= scale;
+    if (i < per) {
+        const int co = i / 320, r = i - co * 320, d = r >> 6, ci = r & 63;
+        dw[(size_t)co * 320 + ci * 5 + d] = s;
+    } else if (i - per < C) {
+        db[i - per] = s;
     }
 }
 
@@ -1481,7 +1499,7 @@ extern "C" int stof_train_wgrad(const float* x, const float* dy, float* dw, floa
         else hipLaunchKernelGGL(conv_wgrad_cl_kernel<7>, grid, dim3(256), 0, s, p);
     }
     const int total = K * p.cout_pad * p.cin_pad + p.cout_pad;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, p.part, p.dbpart, dw, db, G, K, cout, cin,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(64 * WRED_SLICES), 0, s, p.part, p.dbpart, dw, db, G, K, cout, cin,
                        p.cout_pad, p.cin_pad, out_scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
@@ -1576,7 +1594,8 @@ extern "C" int stof_train_sgb_contract_wgrad(const float* gpool, const uint8_t* 
     static stof::LdsLimitOnce once;
     if (int st = once.ensure(reinterpret_cast<const void*>(&sgb_contract_wgrad_kernel), 160 * 1024)) return st;
     hipLaunchKernelGGL(sgb_contract_wgrad_kernel, dim3(G, C / SGBW_CH), dim3(512), lds, s, p);
-    hipLaunchKernelGGL(sgb_wgrad_reduce_kernel, dim3(blocks_for((long long)C * 320)), dim3(256), 0, s, p.part, p.dbpart, dw, db, G, C, out_scale);
+    hipLaunchKernelGGL(sgb_wgrad_reduce_kernel, dim3((unsigned)((C * 321 + 63) / 64)), dim3(64 * WRED_SLICES), 0, s, p.part, p.dbpart, dw, db, G, C,
+                       out_scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
