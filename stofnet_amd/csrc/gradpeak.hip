@@ -1,14 +1,17 @@
 // GradPeak (models/gradpeak.py:8-133) on gfx950.
 //
-//   gradpeak_rows_kernel<MOMENTS>   grad_peak_detect on envelope rows in HBM, one wavefront per row (gradpeak_core.h):
-//                                   MOMENTS = true is the pre-pass of the default threshold (Q7: the std of the WHOLE
-//                                   batch of smoothed gradients, :18), MOMENTS = false detects and pairs
+//   gradpeak_rows_kernel<MOMENTS>   grad_peak_detect on envelope rows in HBM, one wavefront per row (gradpeak_core.h's block
+//                                   streamer): MOMENTS = true is the pre-pass of the default threshold (Q7: the std of the
+//                                   WHOLE batch of smoothed gradients, :18), MOMENTS = false detects and pairs
+//   gradpeak_split_kernel<MOMENTS>  the same for few long rows: 1, 2 or 4 waves share a row's iterations
 //   gradpeak_threshold_kernel       thres_pos = std**16 * 1.2e13 from the (all-reduced) moments, on the device
-//   toa_fused_kernel                toa_detect (:99-116) for an explicit threshold in ONE launch: a wavefront takes a
-//                                   pair of waveforms through FFT -> Hilbert filter -> inverse FFT (fft_small.h, LDS),
-//                                   turns the analytic signals into the two envelopes in place and streams them
+//   toa_fused_ct_kernel<N, ...>,    toa_detect (:99-116) from the waveforms with the envelope kept in LDS: a pair of rows
+//   toa_fused_kernel                goes through FFT -> Hilbert filter -> inverse FFT (compile-time plan for 1536 / 2000 /
+//                                   2048 samples, run-time plan otherwise), becomes two envelopes in place and is streamed
 //                                   through gradient -> Gaussian blur -> threshold crossings -> hysteresis pairing ->
-//                                   echo_max reduction without the envelope ever leaving LDS
+//                                   echo_max reduction (explicit threshold, one launch), or through the moments pre-pass
+//                                   (MOMENTS: the envelope is also stored for the detection launch)
+//   gradpeak_flags_kernel           detection from a smoothed gradient kept by stof_gradpeak_moments_store (r2 route, ABI only)
 // One host read per call at most (flags = {Q9, Kmax}); no host sync inside.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -252,7 +255,7 @@ bool launch_split(const float* env, int64_t N, const Config& cf, const float* ta
 }
 
 // Detection from the smoothed gradient kept by the moments pass (row-major, 64 values per iteration): the loads do not
-// depend on anything computed here, so several iterations are requested ahead; flags, edges and pairing as in stream_rows.
+// depend on anything computed here, so several iterations are requested ahead; flags, edges and pairing word by word.
 __global__ __launch_bounds__(64 * ROWS_WAVES) void gradpeak_flags_kernel(const float* __restrict__ env, const float* __restrict__ blurred,
                                                                          long long N, Config cf, const float* __restrict__ th_dev,
                                                                          float* __restrict__ echoes, float* __restrict__ reduced,

@@ -1,18 +1,21 @@
-// grad_peak_detect (models/gradpeak.py:8-68) for one row per wavefront (or two rows that share one envelope image),
-// streamed 64 samples at a time -- device code shared by gradpeak.hip's stand-alone kernels (envelope rows in HBM) and
-// by the fused toa_detect kernel (envelope rows in LDS, straight out of the inverse FFT):
+// grad_peak_detect (models/gradpeak.py:8-68) for one row per wavefront -- device code shared by gradpeak.hip's stand-alone
+// kernels (envelope rows in HBM) and by the fused toa_detect kernels (envelope rows in LDS, straight out of the inverse
+// FFT):
 //
-//   gradient  torch.gradient(env, spacing = g)  (:14): central differences / (2 g), one-sided / g at both ends,
-//             true IEEE divisions so every value is the reference's float
+//   gradient  torch.gradient(env, spacing = g)  (:14): central differences / (2 g), one-sided / g at both ends; every
+//             value is the reference's float (IEEE division, or its correctly rounded constant-divisor form)
 //   blur      zero padded correlation with the 2 rad + 1 Gaussian taps (:15, :89-96), fmaf chain in tap order
 //   edges     rising edges of (blur > th) and (blur < -th/4) (:23-30) as 64-bit ballot masks; an edge sits at the
 //             last-false sample (diff == 1 at i means flag[i] = 0, flag[i + 1] = 1)
 //   pairing   every falling-slope edge `am` takes the nearest rising-slope edge `ap` <= am, gate
 //             ival_min < am - ap < ival_max, first am per distinct ap (:42-60)
 //
-// The smoothed gradient never leaves registers: gradients go through a small ring in LDS (the blur needs 2 rad + 1
-// neighbours), the two comparison flags of 64 consecutive samples are two ballots, and the pairing runs on those words
-// one iteration later (an edge at the last lane needs the first flag of the next word).
+// The smoothed gradient never leaves registers: gradients go through a small buffer in LDS (the blur needs 2 rad + 1
+// neighbours), the two comparison flags of 64 consecutive samples are two ballots.  Two streamers:
+//   stream_blocks  (r3, every kernel): four 64-sample words per iteration, flag words collected 64 at a time and paired
+//                  together (pair_batch) or stored for a later pairing (pair_stored_words)
+//   stream_words   (r2): one word per iteration; kept for the pre-pass that stores the smoothed gradient
+//                  (stof_gradpeak_moments_store)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -237,30 +240,6 @@ __device__ __forceinline__ void stream_words(const Config& cf, const float* __re
             sink(c, r, P, M, V, in_row ? sm[r] : 0.f);
         }
     }
-}
-
-// The whole row in one call, with the pairing (MOMENTS = false) or the sums of the blurred gradient (MOMENTS = true,
-// the Q7 pre-pass) applied on the fly.
-//   env_at(r, i)     : envelope of row r at sample i (amplitude of a kept peak)
-template <int NR, bool MOMENTS, class EnvPair, class EnvAt>
-__device__ __forceinline__ void stream_rows(const Config& cf, const float* __restrict__ taps, float* __restrict__ ring,
-                                            int lane, EnvPair env_pair, EnvAt env_at, float* const (&out)[NR],
-                                            RowState (&st)[NR], double (&mom)[2]) {
-    const int rad = cf.radius;
-    stream_words<NR>(cf, taps, ring, lane, env_pair, 0, word_count(cf.L, rad) - 1, true,
-                     [&](int c, int r, unsigned long long P, unsigned long long M, unsigned long long V, float sm) {
-                         if (MOMENTS) {
-                             mom[0] += (double)sm;                         // lanes outside the row deliver 0
-                             mom[1] += (double)sm * (double)sm;
-                             return;
-                         }
-                         if (c > 0) {                                      // an edge at the last lane needs this word's first flag
-                             const unsigned long long EP = ~st[r].P & ((st[r].P >> 1) | (P << 63)) & st[r].V;
-                             const unsigned long long EM = ~st[r].M & ((st[r].M >> 1) | (M << 63)) & st[r].V;
-                             pair_word(st[r], 64 * (c - 1) - rad, EP, EM, lane, cf, out[r], [&](int idx) { return env_at(r, idx); });
-                         }
-                         st[r].P = P; st[r].M = M; st[r].V = V;
-                     });
 }
 
 // ----------------------------------------------------------------------------------------------------------------
