@@ -1134,28 +1134,50 @@ __global__ __launch_bounds__(64 * WRED_SLICES) void sgb_wgrad_reduce_kernel(cons
 }
 
 // conv1 (1 -> 64, k9, pad 4) + ReLU, channel-last output; and its weight gradient
+// A work-group takes 64 consecutive time rows of one waveform: thread = (row r = tid >> 4 (+ 16 j), channel quad q = tid & 15)
+// with its 4 x 9 weights in registers; the 72-sample input window and the weights go through LDS once per group.  (One
+// thread per (row, quad) reading its 36 weights and 9 samples with vector loads was bound by the texture addresser --
+// a wave's 64 addresses cost the same whatever the width: 79 us for the 131 MB of output at batch 256.)
+constexpr int C1_ROWS = 64;
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y, int N, int L) {
-    const long long i = blockIdx.x * 256ll + threadIdx.x;      // (n, t, quad of channels)
-    if (i >= (long long)N * L * 16) return;
-    const int q = (int)(i & 15);
-    const long long nt = i >> 4;
-    const int t = (int)(nt % L);
-    const float* xr = x + (nt - t);
-    float xv[9];
-#pragma unroll
-    for (int d = 0; d < 9; ++d) { const int u = t + d - 4; xv[d] = (u >= 0 && u < L) ? xr[u] : 0.f; }
-    float4 o;
-    float* op = &o.x;
+    __shared__ float ws[64 * 9 + 64];
+    __shared__ float xs[C1_ROWS + 8];
+    const int tid = threadIdx.x, q = tid & 15, r = tid >> 4;
+    const int tiles = (L + C1_ROWS - 1) / C1_ROWS;
+    const long long n = blockIdx.x / tiles;
+    const int t0 = (int)(blockIdx.x - n * tiles) * C1_ROWS;
+    for (int i = tid; i < 64 * 9 + 64; i += 256) ws[i] = i < 64 * 9 ? w[i] : b[i - 64 * 9];
+    if (tid < C1_ROWS + 8) {
+        const int u = t0 + tid - 4;
+        xs[tid] = (u >= 0 && u < L) ? x[n * L + u] : 0.f;
+    }
+    __syncthreads();
+    float wr[4][9], br[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int ch = 4 * q + e;
-        float a = b[ch];
+        br[e] = ws[64 * 9 + 4 * q + e];
 #pragma unroll
-        for (int d = 0; d < 9; ++d) a = fmaf(w[ch * 9 + d], xv[d], a);
-        op[e] = fmaxf(a, 0.f);
+        for (int d = 0; d < 9; ++d) wr[e][d] = ws[(4 * q + e) * 9 + d];
     }
-    *reinterpret_cast<float4*>(y + nt * 64 + 4 * q) = o;
+#pragma unroll
+    for (int j = 0; j < C1_ROWS / 16; ++j) {
+        const int rr = r + 16 * j, t = t0 + rr;
+        if (t >= L) break;
+        float xv[9];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) xv[d] = xs[rr + d];
+        float4 o;
+        float* op = &o.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = br[e];
+#pragma unroll
+            for (int d = 0; d < 9; ++d) a = fmaf(wr[e][d], xv[d], a);
+            op[e] = fmaxf(a, 0.f);
+        }
+        *reinterpret_cast<float4*>(y + (n * L + t) * 64 + 4 * q) = o;
+    }
 }
 
 // dW1[ch][d] += sum_t g'[t][ch] x[t+d-4], db1[ch] += sum_t g'[t][ch], g' = g * relu'(saved conv1 output)
@@ -1164,7 +1186,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
                                                           const float* __restrict__ saved,
                                                           float* __restrict__ copies, int N, int L, int rows_per_block) {
     __shared__ float red[4][64][10];
-    const int tid = threadIdx.x, ch = tid & 63, part = tid >> 6;
+    // (part -- hence the row and its nine input samples -- is wave-uniform: made scalar so that the samples come through the
+    // scalar cache; as vector loads they were nine of the eleven loads per row and the texture addresser was the limit, 149 us)
+    const int tid = threadIdx.x, ch = tid & 63, part = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = blockIdx.x * rows_per_block;                 // N*L < 2^31 is checked by the caller
     const int total = N * L;
     float acc[10];
@@ -1175,9 +1199,18 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
 #pragma unroll 4
     for (int r = r0 + part; r < rend; r += 4) {
         const float* xr = x + (r - t);
-        const float gv = saved[(size_t)r * 64 + ch] > 0.f ? g[(size_t)r * 64 + ch] : 0.f;
+        const float gl = g[(size_t)r * 64 + ch], sl = saved[(size_t)r * 64 + ch];      // (both requested before either is used)
+        const float gv = sl > 0.f ? gl : 0.f;
+        float xv[9];
+        if (t >= 4 && t < L - 4) {                              // (scalar: all nine samples inside the waveform, no guards)
 #pragma unroll
-        for (int d = 0; d < 9; ++d) { const int u = t + d - 4; acc[d] = fmaf(gv, (u >= 0 && u < L) ? xr[u] : 0.f, acc[d]); }
+            for (int d = 0; d < 9; ++d) xv[d] = xr[t + d - 4];
+        } else {
+#pragma unroll
+            for (int d = 0; d < 9; ++d) { const int u = t + d - 4; xv[d] = (u >= 0 && u < L) ? xr[u] : 0.f; }
+        }
+#pragma unroll
+        for (int d = 0; d < 9; ++d) acc[d] = fmaf(gv, xv[d], acc[d]);
         acc[9] += gv;
         t += 4;
         if (t >= L) t -= L;
@@ -1508,7 +1541,7 @@ extern "C" int stof_train_conv1(const float* x, const float* w, const float* b, 
     if (N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     if (N == 0 || L == 0) return STOF_OK;
     if (!x || !w || !b || !y) return STOF_ERR_BAD_ARG;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks_for(N * L * 16)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)(N * ((L + C1_ROWS - 1) / C1_ROWS))), dim3(256), 0, static_cast<hipStream_t>(stream),
                        x, w, b, y, (int)N, (int)L);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
