@@ -306,6 +306,11 @@ int stof_train_pool(const float* c, float* pooled, uint8_t* arg, int64_t N, int6
 int stof_train_pool_bwd(const float* gpool, const uint8_t* arg, const float* c, const float* pooled, float* gc, int64_t N,
                         int64_t L, int64_t P, int32_t C, int32_t scale, void* stream);
 
+/* Data gradient of conv_last (64 -> r channels, k3) on the vector pipe, exact fp32: out[N, L, 64] from dz[N, L, r] and
+ * conv_last.weight in torch layout [r][64][3] = what stof_train_conv computes with the repacked data-gradient weights.
+ * r = 4 or 10; otherwise STOF_ERR_UNSUPPORTED.                                                                        */
+int stof_train_conv_last_dgrad(const float* dz, const float* weight, float* out, int64_t N, int64_t L, int32_t r, void* stream);
+
 /* SemiGlobalBlock backward, contract_conv's weight / bias gradient straight from the pool's SPARSE gradient (one non-zero
  * row per (waveform, window, channel)): dw[C][64][5], db[C] = out_scale * the gradient that stof_train_pool_bwd +
  * stof_train_wgrad(a1, gc, cin 64, cout C, K 5) produce, without the dense [N, L, C] tensor.  gpool / arg / pooled[N, P, C]

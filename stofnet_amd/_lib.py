@@ -111,6 +111,7 @@ _SIGNATURES = {
     'stof_train_sweep_bwd_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'stof_train_sweep_bwd': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
     'stof_train_pool': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_void_p]),
+    'stof_train_conv_last_dgrad': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p]),
     'stof_train_sgb_dgrad_workspace_bytes': (_c.c_size_t, [_c.c_int32]),
     'stof_train_sgb_contract_dgrad': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                                  _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_size_t, _c.c_void_p]),

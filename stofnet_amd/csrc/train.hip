@@ -1133,6 +1133,57 @@ __global__ __launch_bounds__(64 * WRED_SLICES) void sgb_wgrad_reduce_kernel(cons
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Data gradient of conv_last (64 -> r channels, k3): g6[n][t][c] = sum_{o < r, d} dz[n][t - d + 1][o] w[o][c][d].  With
+// r = 10 (or 4) input channels the layer kernels pad to a 64-channel block and spend 116 us at the benched shape on what
+// is 2 GFLOP and 150 MB; here it runs on the vector pipe in exact fp32: a work-group takes 256 rows of one waveform,
+// thread = (channel quad, row lane) keeps its 3 x R x 4 weights in registers and walks 16 rows, the dz rows come from LDS.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int CLD_ROWS = 256;
+template <int R>
+__global__ __launch_bounds__(256) void conv_last_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                              float* __restrict__ out, int N, int L) {
+    constexpr int RP = (R + 3) / 4 * 4;                           // floats per staged row
+    __shared__ __attribute__((aligned(16))) float zs[(CLD_ROWS + 2) * RP];
+    const int tid = threadIdx.x, q = tid & 15, rl = tid >> 4;
+    const int tiles = (L + CLD_ROWS - 1) / CLD_ROWS;
+    const long long n = blockIdx.x / tiles;
+    const int t0 = (int)(blockIdx.x - n * tiles) * CLD_ROWS;
+    float wr[3][R][4];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int o = 0; o < R; ++o)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wr[d][o][e] = w[((size_t)o * 64 + 4 * q + e) * 3 + d];
+    for (int i = tid; i < (CLD_ROWS + 2) * RP; i += 256) {        // rows t0 - 1 .. t0 + CLD_ROWS, zero outside the waveform
+        const int row = i / RP, c = i - row * RP, t = t0 - 1 + row;
+        zs[i] = (c < R && t >= 0 && t < L) ? dz[(n * L + t) * R + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int j = 0; j < CLD_ROWS / 16; ++j) {
+        const int rr = rl + 16 * j, t = t0 + rr;
+        if (t >= L) break;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float* zr = zs + (rr + 2 - d) * RP;             // row t - d + 1  <->  staged row rr + 1 - d + 1
+            float z[RP];
+#pragma unroll
+            for (int k = 0; k < RP / 4; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(zr + 4 * k);
+                z[4 * k] = v.x; z[4 * k + 1] = v.y; z[4 * k + 2] = v.z; z[4 * k + 3] = v.w;
+            }
+#pragma unroll
+            for (int o = 0; o < R; ++o)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(z[o], wr[d][o][e], acc[e]);
+        }
+        *reinterpret_cast<float4*>(out + (n * L + t) * 64 + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 // conv1 (1 -> 64, k9, pad 4) + ReLU, channel-last output; and its weight gradient
 // A work-group takes 64 consecutive time rows of one waveform: thread = (row r = tid >> 4 (+ 16 j), channel quad q = tid & 15)
 // with its 4 x 9 weights in registers; the 72-sample input window and the weights go through LDS once per group.  (One
@@ -1654,6 +1705,21 @@ extern "C" int stof_train_sgb_contract_dgrad(const float* gpool, const uint8_t* 
     p.gpool = gpool; p.arg = arg; p.pooled = pooled; p.wt = wt; p.resid = resid; p.out = out;
     p.nwin = N * P; p.L = (int)L; p.P = (int)P; p.C = C; p.S = scale;
     hipLaunchKernelGGL(sgb_contract_dgrad_kernel, dim3((unsigned)((N * P + SGBD_WAVES - 1) / SGBD_WAVES)), dim3(64 * SGBD_WAVES), 0, s, p);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+// Data gradient of conv_last: out[N, L, 64] from dz[N, L, r] and conv_last.weight[r][64][3] (exact fp32).  r = 4 or 10;
+// other factors return STOF_ERR_UNSUPPORTED (the caller uses stof_train_conv with the repacked weights).
+extern "C" int stof_train_conv_last_dgrad(const float* dz, const float* weight, float* out, int64_t N, int64_t L, int32_t r, void* stream) {
+    if (N < 0 || L < 0 || r < 1) return STOF_ERR_BAD_ARG;
+    if (r != 4 && r != 10) return STOF_ERR_UNSUPPORTED;
+    if (N == 0 || L == 0) return STOF_OK;
+    if (!dz || !weight || !out) return STOF_ERR_BAD_ARG;
+    const int64_t groups = N * ((L + CLD_ROWS - 1) / CLD_ROWS);
+    if (groups > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (r == 10) hipLaunchKernelGGL(conv_last_dgrad_kernel<10>, dim3((unsigned)groups), dim3(256), 0, s, dz, weight, out, (int)N, (int)L);
+    else hipLaunchKernelGGL(conv_last_dgrad_kernel<4>, dim3((unsigned)groups), dim3(256), 0, s, dz, weight, out, (int)N, (int)L);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

@@ -162,7 +162,7 @@ class TrainEngine:
             ys = [t[1 + 2 * k] for k in range(5)]
             saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=t[11], bwd=bwd, n=n, L=L, P=P, rem=rem,
                          _dump=dump, desc=desc, wdev=[p[f'conv{i}.weight'] for i in range(2, 13)],
-                         wc=p.get(sg + 'contract_conv.weight'))
+                         wc=p.get(sg + 'contract_conv.weight'), wl=p['conv_last.weight'])
             return z, saved
         if self.sgb:
             x0, c, pooled, arg, e = self._sgb_forward(a1, fwd[sg + 'contract_conv'], p[sg + 'contract_conv.bias'],
@@ -185,7 +185,7 @@ class TrainEngine:
         if not keep:
             return z.view(n, L * r), None
         saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=x6, bwd=bwd, n=n, L=L, P=P, rem=rem,
-                     wc=p.get('semi_global_block.contract_conv.weight'))
+                     wc=p.get('semi_global_block.contract_conv.weight'), wl=p['conv_last.weight'])
         return z.view(n, L * r), saved
 
     def _sgb_head(self, a1, w_contract, b_contract, w_expand, b_expand):
@@ -228,7 +228,13 @@ class TrainEngine:
         self.g = g
         dz = dpred.view(n, L, r)
         self._wgrad(x6, dz, 'conv_last', 64, r, 3)
-        g6 = self._conv(dz, bwd['conv_last'], None, r, 64, 3)
+        # conv_last's data gradient: r input channels would be padded to a 64-channel block by the layer kernels
+        g6 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
+        code = lib.stof_train_conv_last_dgrad(_lib.ptr(dz.contiguous()), _lib.ptr(saved['wl'].contiguous()), _lib.ptr(g6), n, L, r, st)
+        if code == _lib.STOF_ERR_UNSUPPORTED:
+            g6 = self._conv(dz, bwd['conv_last'], None, r, 64, 3)
+        else:
+            _lib.check(code, 'stof_train_conv_last_dgrad')
         self._wgrad(xs[5], g6, 'conv12', 64, 64, 7)
         if saved.get('_dump') is not None and 'conv12' not in bwd:
             # the eleven data-gradient convolutions conv12^T .. conv2^T as ONE backward sweep (stof_train_sweep_bwd), then the

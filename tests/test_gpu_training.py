@@ -119,6 +119,23 @@ def test_sgb_sparse_contract_weight_gradient_matches_dense_route(dev, n, L, S, C
                                              n, L, P, 64, S, 1.0, _lib.ptr(ws2), ws2.numel(), st) == _lib.STOF_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize('r,n,L', [(10, 3, 2000), (4, 2, 517), (10, 1, 7)])
+def test_conv_last_data_gradient_kernel(dev, r, n, L):
+    """stof_train_conv_last_dgrad (vector-pipe fp32) against conv_transpose1d in float64: rows at both ends of a waveform,
+    a waveform shorter than a work-group's tile, a ragged last tile."""
+    from stofnet_amd import _lib
+    lib, st = _lib.lib(), _lib.stream_ptr(dev)
+    gen = torch.Generator(device='cpu').manual_seed(r * 100 + L)
+    dz = torch.randn(n, L, r, generator=gen).to(dev)
+    w = torch.randn(r, 64, 3, generator=gen).to(dev)
+    out = torch.full((n, L, 64), float('nan'), device=dev)
+    _lib.check(lib.stof_train_conv_last_dgrad(_lib.ptr(dz), _lib.ptr(w), _lib.ptr(out), n, L, r, st), 'conv_last_dgrad')
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv_transpose1d(dz.double().cpu().permute(0, 2, 1), w.double().cpu(), padding=1).permute(0, 2, 1)
+    assert relerr(out.cpu().numpy(), ref.numpy()) < 2e-6
+    assert lib.stof_train_conv_last_dgrad(_lib.ptr(dz), _lib.ptr(w), _lib.ptr(out), n, L, 20, st) == _lib.STOF_ERR_UNSUPPORTED
+
+
 
 @pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
 @pytest.mark.parametrize('r,sgs,L', [(4, 80, 400), (10, 80, 336), (4, 1, 250)])
