@@ -1343,18 +1343,30 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restri
 }
 
 // ge[n][w][ch] = lrelu'(e) * sum_{t in window w} g[n][t][ch]
+// One wave per (n, w): lane = (row subset part = lane >> 4, channel quad c4 = lane & 15); a lane adds the rows k = part mod 4
+// of the window with 16-byte loads, the four subsets are combined in a fixed order.  (One thread per channel walking the 80
+// rows with dword loads: 48 us for the 131 MB at batch 256.)
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ g, const float* __restrict__ e,
                                                            float* __restrict__ ge, int N, int L, int P, int rem_half, int S) {
-    const long long i = blockIdx.x * 256ll + threadIdx.x;      // (n, w, ch)
-    if (i >= (long long)N * P * 64) return;
-    const int ch = (int)(i & 63);
-    const long long nw = i >> 6;
+    const long long nw = blockIdx.x * 4ll + (threadIdx.x >> 6);  // (n, w)
+    if (nw >= (long long)N * P) return;
+    const int lane = threadIdx.x & 63, part = lane >> 4, c4 = lane & 15;
     const int w = (int)(nw % P);
     const long long n = nw / P;
-    const float* src = g + (n * L + rem_half + (long long)w * S) * 64 + ch;
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += src[(long long)k * 64];
-    ge[i] = e[i] > 0.f ? s : 0.01f * s;
+    const float* src = g + (n * L + rem_half + (long long)w * S) * 64 + 4 * c4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 5
+    for (int k = part; k < S; k += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (long long)k * 64);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    s.x += __shfl_xor(s.x, 16); s.y += __shfl_xor(s.y, 16); s.z += __shfl_xor(s.z, 16); s.w += __shfl_xor(s.w, 16);
+    s.x += __shfl_xor(s.x, 32); s.y += __shfl_xor(s.y, 32); s.z += __shfl_xor(s.z, 32); s.w += __shfl_xor(s.w, 32);
+    if (part == 0) {
+        const float4 ev = *reinterpret_cast<const float4*>(e + nw * 64 + 4 * c4);
+        *reinterpret_cast<float4*>(ge + nw * 64 + 4 * c4) = make_float4(ev.x > 0.f ? s.x : 0.01f * s.x, ev.y > 0.f ? s.y : 0.01f * s.y,
+                                                                        ev.z > 0.f ? s.z : 0.01f * s.z, ev.w > 0.f ? s.w : 0.01f * s.w);
+    }
 }
 
 // ---- loss (main.py:228-232): target = 20 * blur7(onehot(gt)) / max(blur); MSE + lambda * mean|pred|
@@ -1453,8 +1465,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ out, long long n) {
-    const long long i = blockIdx.x * 256ll + threadIdx.x;
-    if (i < n) out[i] = a[i] + b[i];
+    const long long i = blockIdx.x * 256ll + threadIdx.x;        // four elements per thread where the arrays allow 16-byte accesses
+    const bool vec = ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(out)) & 15) == 0;
+    const long long n4 = vec ? n / 4 : 0;
+    if (i < n4) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+    const long long j = 4 * n4 + i;                              // the rest (everything, for unaligned arrays)
+    if (!vec) { for (long long k = j; k < n; k += (long long)gridDim.x * 256) out[k] = a[k] + b[k]; }
+    else if (j < n) out[j] = a[j] + b[j];
 }
 
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
@@ -1758,7 +1778,7 @@ extern "C" int stof_train_upsample_bwd(const float* g, const float* e, float* ge
     if (N < 0 || L < 0 || P < 0 || scale < 1 || rem_half < 0 || rem_half + P * scale > L) return STOF_ERR_BAD_ARG;
     if (N * P == 0) return STOF_OK;
     if (!g || !e || !ge) return STOF_ERR_BAD_ARG;
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(blocks_for(N * P * 64)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((N * P + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        g, e, ge, (int)N, (int)L, (int)P, rem_half, scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
@@ -1818,6 +1838,8 @@ extern "C" int stof_train_add(const float* a, const float* b, float* out, int64_
     if (n < 0) return STOF_ERR_BAD_ARG;
     if (n == 0) return STOF_OK;
     if (!a || !b || !out) return STOF_ERR_BAD_ARG;
-    hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, (long long)n);
+    const bool vec = ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(out)) & 15) == 0;
+    const long long threads = vec ? (n / 4 > 4 ? n / 4 : 4) : n;                 // (the kernel makes the same choice)
+    hipLaunchKernelGGL(add_kernel, dim3(blocks_for(threads)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, (long long)n);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
