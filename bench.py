@@ -444,9 +444,15 @@ def train_bench(args):
                         {'rows_per_gpu': nb, 'L': L, 'upsample_factor': R, 'precision': args.train_precision,
                          'trainer': args.trainer,
                          'parallelism': f'ddp{d.world}: one flat 2.58 MB gradient all-reduce per step'})
-        out['roofline'] = {'bound': 'mfma', 'kernel': f'whole step (conv_cl_kernel + conv_wgrad kernels, {args.train_precision} MFMA)',
+        # `achieved` counts the ALGORITHMIC flops of the step (what the reference's dense autograd does).  Since r3 the two backward
+        # passes of the SemiGlobalBlock's contract convolution (22.6 % of that count) work on the max-pool's sparse gradient and are
+        # not multiplied out; `executed` leaves them out, i.e. it is the matrix-pipe work actually done per second.
+        sparse_sgb = os.environ.get('STOF_TRAIN_SGB_SPARSE', '1') != '0'
+        executed = (flops - (2.0 * 2.0 * nb * L * 163840 if sparse_sgb else 0.0)) * args.steps / dt / 1e12
+        out['roofline'] = {'bound': 'mfma', 'kernel': f'whole step (sweeps + conv_wgrad / conv_cl16 kernels, {args.train_precision} MFMA)',
                            'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                           'frac': round(achieved / peak, 4), 'traffic': None}
+                           'frac': round(achieved / peak, 4), 'traffic': None,
+                           'executed': round(executed, 2), 'executed_frac': round(executed / peak, 4)}
         out['final_loss'] = float(last['loss'])
         out['ranks'] = census
         if not args.no_cpu_baseline:       # rank 0 only; at N > 1 the other ranks wait in finish()'s barrier meanwhile
