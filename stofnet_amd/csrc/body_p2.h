@@ -1,0 +1,658 @@
+// Body sweep, round-4 form: the split-fp16 k7 layers run TWO-PASS TILE-MAJOR (included by convstack.hip inside its
+// anonymous namespace; shares BodyParams / BodyLds / the packed blob with body_sweep_kernel, whose schedule -- rings, lags,
+// in-place residual stream, one barrier per layer -- is unchanged: oracle/sweep_emulator.py still describes it).
+//
+// What changed and why (tools/micro/sweep_waves.hip, tools/micro/gen_issue_cost.py, profiles/r04_*.jsonl):
+//  * one wave per SIMD issues a v_mfma_f32_16x16x32_f16 every 16.5 cycles and can slide TWO 4-cycle instructions (VALU,
+//    ds_read_b128) behind each for nothing; a third costs its full issue time.  The r3 kernel ran a layer's 14 chunks
+//    chunk-major and hid the epilogue (accumulator read, residual add or leaky ReLU, fp16 split, ring store: ~46 VALU per
+//    16-row tile) behind the 12 MFMAs of a tile's last two chunks: 4 per MFMA, so the tail ran at ~24 cycles per MFMA and the
+//    last tile's epilogue plus the layer set-up stayed exposed (3.8 k + 1.0 k of a layer's 13.6 k cycles).
+//  * here a wave keeps HALF a layer's weights resident (7 chunks x 4 fragments = 112 registers per half, two halves
+//    double-buffered) and sweeps its six 16-row N-tiles twice: pass A = chunks 0..6 of every tile, pass B = chunks 7..13
+//    with the epilogue of tile n-1 cut into seven pieces behind tile n's 42 MFMAs (<= 8 VALU per 6 MFMAs).  Per accumulator
+//    the summation order (chunk 0..13; hi*hi, hi*lo, lo*hi) is the r3 order, so every output bit is unchanged.
+//  * the other half's 28 fragments are requested a whole pass (~4 k cycles) before their first use, one chunk per tile, so
+//    the L1 (64 B/clk/CU; a layer's fragments are 224 KiB per CU) never sees a burst -- a fully weight-resident tile-major
+//    layer has to reload all 56 fragments inside its last tile and was slower than the r3 form.
+//  * the kinds of a step's layers alternate (leaky ReLU, residual add), so the step runs them as straight-line PAIRS: a branch
+//    between two 500-MFMA bodies that both redefine 224 weight registers made the compiler reconcile them with ~120 moves
+//    and a vmcnt(0) at every layer end.
+template <int S, int RING, int RAWRING, bool DUMP = false, bool BWD = false>
+__global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams p) {
+    constexpr int PREC = STOF_PREC_F16X3;
+    constexpr int NCHUNK_STEP = 11 * BODY_CHUNKS_K7;          // k7 weight chunks of a sweep step (conv_last's follow them in the blob)
+    static_assert((RING & (RING - 1)) == 0 && (RAWRING & (RAWRING - 1)) == 0, "rings are powers of two");
+    static_assert(S % 64 == 0 && S + 36 <= RING && S + 42 <= RAWRING, "ring must hold the live span");
+    constexpr int RF = ROWF16;
+    constexpr int ROWB = RF * 4;
+    using Lds = BodyLds<S, RING, RAWRING, RF>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const Xr = reinterpret_cast<char*>(smem + Lds::X);
+    char* const Yr = reinterpret_cast<char*>(smem + Lds::Y);
+    float* const rawr = smem + Lds::RAW;
+    float* const biasl = smem + Lds::BIAS;
+    float* const sgl = smem + Lds::SGL;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = wave & 1, ni = wave >> 1;
+
+    const int n0 = blockIdx.x * p.wf_per_wg;
+    const int n1 = min(p.N, n0 + p.wf_per_wg);
+    if (n0 >= n1) return;
+    if (p.run_if != nullptr && *p.run_if == 0) return;
+    const int Ltrue = p.L, r = p.r;
+    const int L = p.seg_len + 2 * p.halo;        // rows of one (virtual) waveform in the stream
+    const int Lp = L + GAP;
+    const int gend = (n1 - n0) * Lp;             // local stream rows [0, gend)
+    const int seg_mask = (1 << p.nseg_log2) - 1;
+    const bool seg_mode = p.nseg_log2 > 0;
+    auto vmap = [&](int nv, int tl, int& n, int& tt) {
+        n = nv >> p.nseg_log2;
+        tt = (nv & seg_mask) * p.seg_len - p.halo + tl;
+    };
+
+    // ---- one-time setup: zero rings, biases to LDS, conv1 taps to registers
+    for (int i = tid; i < Lds::RAW + RAWRING; i += 256) smem[i] = 0.f;
+    for (int i = tid; i < 13 * 64; i += 256) biasl[i] = p.bias[i];
+    const int cq = tid & 15, rl = tid >> 4;
+    float w1[4][9], b1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int d = 0; d < 9; ++d) w1[i][d] = p.c1[(4 * cq + i) * 10 + d];
+        b1[i] = p.c1[(4 * cq + i) * 10 + 9];
+    }
+    __syncthreads();
+    auto decode_row = [&](int nB, int tB, int off, int& n, int& t) {
+        n = nB;
+        t = tB + off;
+        if (Lp >= 2 * S) {
+            if (t >= Lp) { t -= Lp; n += 1; }
+        } else {
+            while (t >= Lp) { t -= Lp; n += 1; }
+        }
+    };
+
+    // relu(conv1(x)) + SemiGlobalBlock contribution for stream rows [rstart, rstart+S) -> ring dst (as body_sweep_kernel)
+    const float one_x0 = opaque_one();
+    auto x0_pass = [&](char* dst, int rstart, int nR, int tR, bool dump_it) {
+        constexpr int NIT = S / 16;
+        float* const dump0 = (DUMP && dump_it) ? p.dump : nullptr;
+        const int g0 = rstart + rl * NIT;
+        if (!seg_mode && rstart >= 0 && rstart + S <= gend && tR + S <= L &&
+            (p.sgb == nullptr || (tR >= p.rem_half && tR + S - p.rem_half <= SGB_SCALE * p.P))) {
+            float xs[NIT + 8];
+#pragma unroll
+            for (int i = 0; i < NIT + 8; ++i) xs[i] = rawr[(g0 - 4 + i) & (RAWRING - 1)];
+            float4 sgA = make_float4(0.f, 0.f, 0.f, 0.f), sgB = sgA;
+            int sw = NIT;
+            if (p.sgb != nullptr) {
+                const int pos0 = tR + rl * NIT - p.rem_half;
+                const int w0 = pos0 / SGB_SCALE;
+                sw = SGB_SCALE * (w0 + 1) - pos0;
+                const int wid = (n0 + nR) * p.P + w0;
+                sgA = ld4(sgl + (wid & 7) * NF + 4 * cq);
+                sgB = ld4(sgl + ((wid + 1) & 7) * NF + 4 * cq);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const bool first = it < sw;
+                const float sg[4] = {first ? sgA.x : sgB.x, first ? sgA.y : sgB.y, first ? sgA.z : sgB.z, first ? sgA.w : sgB.w};
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float a = b1[i];
+#pragma unroll
+                    for (int d = 0; d < 9; ++d) a = fmaf(w1[i][d], xs[it + d], a);
+                    v[i] = fmaxf(a, 0.f) + sg[i];
+                }
+                char* const row = dst + ((g0 + it) & (RING - 1)) * ROWB;
+                if (dump0 != nullptr)
+                    st4(dump0 + ((size_t)(n0 + nR) * Ltrue + tR + rl * NIT + it) * NF + 4 * cq, make_float4(v[0], v[1], v[2], v[3]));
+                const half2v h01 = cvt_h2(v[0], v[1]), h23 = cvt_h2(v[2], v[3]);
+                const half2v l01 = cvt_h2(mix_sub(h01[0], v[0], one_x0), mix_sub(h01[1], v[1], one_x0));
+                const half2v l23 = cvt_h2(mix_sub(h23[0], v[2], one_x0), mix_sub(h23[1], v[3], one_x0));
+                *reinterpret_cast<uint2*>(row + 8 * cq) = make_uint2(h2_bits(h01), h2_bits(h23));
+                *reinterpret_cast<uint2*>(row + 128 + 8 * cq) = make_uint2(h2_bits(l01), h2_bits(l23));
+            }
+            return;
+        }
+        int nb, tb;
+        decode_row(nR, tR, rl * NIT, nb, tb);
+        float xs[NIT + 8];
+#pragma unroll
+        for (int i = 0; i < NIT + 8; ++i) xs[i] = rawr[(g0 - 4 + i) & (RAWRING - 1)];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int g = g0 + it;
+            int t = tb + it;
+            int nl = nb;
+            if (t >= Lp) { t -= Lp; nl += 1; }
+            int nw, tw;
+            vmap(n0 + nl, t, nw, tw);
+            const bool ok = (g >= 0) && (g < gend) && (t < L) && (tw >= 0) && (tw < Ltrue);
+            float4 sg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.sgb != nullptr && ok) {
+                const int pos = tw - p.rem_half;
+                if (pos >= 0 && pos < SGB_SCALE * p.P) {
+                    const int wid = nw * p.P + pos / SGB_SCALE;
+                    sg = seg_mode ? ld4(p.sgb + (size_t)wid * NF + 4 * cq) : ld4(sgl + (wid & 7) * NF + 4 * cq);
+                }
+            }
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a = b1[i];
+#pragma unroll
+                for (int d = 0; d < 9; ++d) a = fmaf(w1[i][d], xs[it + d], a);
+                v[i] = fmaxf(a, 0.f);
+            }
+            const float4 o = ok ? make_float4(v[0] + sg.x, v[1] + sg.y, v[2] + sg.z, v[3] + sg.w)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dump0 != nullptr && ok && t >= p.halo && t < p.halo + p.seg_len)
+                st4(dump0 + ((size_t)nw * Ltrue + tw) * NF + 4 * cq, o);
+            store_act4<PREC>(dst + ((g0 + it) & (RING - 1)) * ROWB, 4 * cq, o);
+        }
+    };
+
+    float raw_next = 0.f, sg_next = 0.f;
+    int sg_slot = -1;
+    auto fetch_step = [&](int Fn, int nB, int tB) {
+        raw_next = 0.f;
+        if (tid < S) {
+            const int g = Fn + 4 - S + tid;
+            int nl, t;
+            decode_row(nB, tB, 4 + tid, nl, t);
+            int nw, tw;
+            vmap(n0 + nl, t, nw, tw);
+            if (g < gend && t < L && tw >= 0 && tw < Ltrue) raw_next = p.x[(size_t)nw * Ltrue + tw];
+        }
+        sg_slot = -1;
+        if (p.sgb != nullptr && !seg_mode) {
+            const int q = tid >> 6;
+            const int off = q == 3 ? S - 1 : 80 * q;
+            const int g = Fn - S + off;
+            int nl, t;
+            decode_row(nB, tB, off, nl, t);
+            const int pos = t - p.rem_half;
+            if (g < gend && t < L && pos >= 0 && pos < SGB_SCALE * p.P) {
+                const int wid = (n0 + nl) * p.P + pos / SGB_SCALE;
+                sg_slot = wid & 7;
+                sg_next = p.sgb[(size_t)wid * NF + (tid & 63)];
+            }
+        }
+    };
+    static_assert(S <= 240 && S > 160, "probe offsets {0, 80, 160, S-1} assume 160 < S <= 240");
+    if constexpr (!BWD) {
+        if (tid < 4 && tid < L) {
+            int nw, tw;
+            vmap(n0, tid, nw, tw);
+            if (tw >= 0 && tw < Ltrue) rawr[tid] = p.x[(size_t)nw * Ltrue + tw];
+        }
+        fetch_step(S, 0, 0);
+    }
+    auto gin_pass = [&](char* dst, int rstart, int nR, int tR) {
+        constexpr int NIT = S / 16;
+        const int g0 = rstart + rl * NIT;
+        int nb, tb;
+        decode_row(nR, tR, rl * NIT, nb, tb);
+        float4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int g = g0 + it;
+            int t = tb + it, nl = nb;
+            if (t >= Lp) { t -= Lp; nl += 1; }
+            int nw, tw;
+            vmap(n0 + nl, t, nw, tw);
+            const bool ok = (g >= 0) && (g < gend) && (t < L) && (tw >= 0) && (tw < Ltrue);
+            v[it] = ok ? ld4(p.gin + ((size_t)nw * Ltrue + tw) * NF + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) store_act4<PREC>(dst + ((g0 + it) & (RING - 1)) * ROWB, 4 * cq, v[it]);
+    };
+
+    // ---- weights: two half-layer buffers of 7 chunks x 4 fragments (M-tile 0 hi | lo, M-tile 1 hi | lo), see the header
+    constexpr int HC = BODY_CHUNKS_K7 / 2;
+    const uint4* const wbase = reinterpret_cast<const uint4*>(p.chunks) + mi * 64 + lane;
+    auto wload = [&](int c, int f) -> uint4 { return wbase[((size_t)c * FRAGS_PER_CHUNK + f) * 128]; };
+    uint4 W[2][HC][FRAGS_PER_CHUNK];
+#pragma unroll
+    for (int c = 0; c < HC; ++c)
+#pragma unroll
+        for (int f = 0; f < FRAGS_PER_CHUNK; ++f) W[0][c][f] = wload(c, f);
+
+#ifdef STOF_STAMPS
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = stamp();
+    const unsigned long long tstart = tprev;
+#endif
+    constexpr int NN = S / 32;                    // N-tiles (16 rows) per wave
+    static_assert(NN == 6, "the two-pass layer is written for six N-tiles per wave (S = 192)");
+    constexpr int PD = 2, NB = PD + 1;            // activation fragments are requested PD chunks ahead of their MFMAs
+    const int i16 = lane & 15, q4 = lane >> 4;
+    auto mfma16 = [](const uint4& a, const uint4& b, floatx4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(a), as_h8(b), c, 0, 0, 0);
+    };
+    const float one = opaque_one();
+
+    const int nsteps = (gend - GAP + LAG_LAST + S - 1) / S;
+    int nS = 0, tS = 0;                           // waveform / time of stream row F - S (wave-uniform)
+    int F = 0;
+
+    // One k7 layer.  KIND: 0 = residual add in place, 1 = leaky ReLU (forward), 2 = plain, 3 = times lrelu'(saved) (backward)
+    auto layer = [&](auto kind_c, const int j) {
+        constexpr int KIND = decltype(kind_c)::value;
+        constexpr bool INPL = KIND == 0;
+        int nR = nS, tR = tS - 3 * j;             // waveform / time of the layer's first row R0 = F - S - lag (may precede the stream)
+        while (tR < 0) { tR += Lp; nR -= 1; }
+        const char* const src = (j & 1) ? Xr : Yr;             // odd sweep layers read ring X and write ring Y
+        char* const dst = (j & 1) ? Yr : Xr;
+        const int R0 = F - S - 3 * j;
+        floatx4 bvec[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float4 bb = ld4(biasl + j * 64 + 32 * mi + 8 * q4 + 4 * m);
+            bvec[m][0] = bb.x; bvec[m][1] = bb.y; bvec[m][2] = bb.z; bvec[m][3] = bb.w;
+        }
+        const int rbase = R0 + 16 * NN * ni + i16 - 3;          // row of N-tile 0, tap 0
+        const int cbyte = 16 * q4;
+        auto bload = [&](uint4 (&b)[2], int n, int cc) {
+            const int d = cc >> 1, hh = cc & 1;
+            const char* row = src + ((rbase + 16 * n + d) & (RING - 1)) * ROWB + 64 * hh + cbyte;
+            b[0] = ldq(row);
+            b[1] = ldq(row + 128);
+        };
+        auto row_of = [&](int n, bool& valid, int& slot, int& nw, int& tw, int& tk) {
+            const int off = 16 * (NN * ni + n) + i16;
+            const int g = R0 + off;
+            int nk;
+            decode_row(nR, tR, off, nk, tk);
+            vmap(n0 + nk, tk, nw, tw);
+            valid = (g >= 0) && (g < gend) && (tk < L) && (tw >= 0) && (tw < Ltrue);
+            slot = (g & (RING - 1)) * ROWB + (32 * mi + 8 * q4) * 2;
+        };
+        // wave-uniform: the wave's 96-row span inside one waveform (and, in segment mode, inside the segment's own rows)?
+        const int offw0 = 16 * NN * ni, gw0 = R0 + offw0;
+        int nkw, tkw, nww, tww;
+        decode_row(nR, tR, offw0, nkw, tkw);
+        vmap(n0 + nkw, tkw, nww, tww);
+        const bool span_ok = (gw0 >= 0) && (gw0 + 16 * NN - 1 < gend) && (tkw + 16 * NN - 1 < L) && (tww >= 0) &&
+                             (tww + 16 * NN - 1 < Ltrue) && (tkw >= p.halo) && (tkw + 16 * NN - 1 < p.halo + p.seg_len);
+        float* const dumpj = DUMP ? p.dump + (size_t)j * p.dump_stride : nullptr;
+        float* dlane = nullptr;
+        long long dstep = 0;
+        if constexpr (DUMP) {
+            if (span_ok) {
+                dlane = dumpj + ((size_t)nww * Ltrue + tww + i16) * NF + 32 * mi + 8 * q4;
+                dstep = 16 * NF;
+            } else {
+                dlane = p.dump + 12 * p.dump_stride + 8 * lane;
+            }
+        }
+        // backward, masked layers: saved activation of the lane's 8 channels of its row of N-tile n (the forward dump's tensor
+        // 1 + 2 k, k = 5 - j/2), requested one tile before the piece that uses it
+        const float* const ysp = (BWD && KIND == 3) ? p.fwd_dump + (size_t)(1 + 2 * (5 - (j >> 1))) * p.dump_stride + 32 * mi + 8 * q4 : nullptr;
+        float4 ysv[2][2];
+        auto ys_load = [&](int n) {
+            if constexpr (KIND == 3) {
+                ysv[n & 1][0] = ysv[n & 1][1] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (span_ok) {
+                    const float* const s0 = ysp + ((size_t)nww * Ltrue + tww + i16 + 16 * n) * NF;
+                    ysv[n & 1][0] = ld4(s0);
+                    ysv[n & 1][1] = ld4(s0 + 4);
+                } else {
+                    bool valid;
+                    int slot, nw, tw, tk;
+                    row_of(n, valid, slot, nw, tw, tk);
+                    if (valid) {
+                        ysv[n & 1][0] = ld4(ysp + ((size_t)nw * Ltrue + tw) * NF);
+                        ysv[n & 1][1] = ld4(ysp + ((size_t)nw * Ltrue + tw) * NF + 4);
+                    }
+                }
+            }
+        };
+        // The epilogue of N-tile n (8 consecutive channels of one row per lane) in seven pieces of <= 8 VALU instructions, piece k
+        // behind chunk k of the NEXT tile's pass B.  Branch-free; rows that are padding are zeroed after the layer (rare).
+        struct Epi { int slot; uint4 oh, ol; float v[8]; unsigned hi[4], lo[4]; };
+        floatx4 acc[NN][2];
+        auto piece = [&](Epi& e, int n, int k) {
+            if (k == 0) {
+                e.slot = ((R0 + 16 * (NN * ni + n) + i16) & (RING - 1)) * ROWB + (32 * mi + 8 * q4) * 2;
+                if constexpr (INPL) { e.oh = ldq(dst + e.slot); e.ol = ldq(dst + e.slot + 128); }
+            } else if (k == 1) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) e.v[x] = acc[n][x >> 2][x & 3];
+            } else if (k == 2 || k == 3) {
+                const int m = k - 2;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int x0 = 4 * m + 2 * pr;
+                    if constexpr (INPL) {
+                        const unsigned hw = m ? (pr == 0 ? e.oh.z : e.oh.w) : (pr == 0 ? e.oh.x : e.oh.y);
+                        const unsigned lw = m ? (pr == 0 ? e.ol.z : e.ol.w) : (pr == 0 ? e.ol.x : e.ol.y);
+                        const half2v h = bits_h2(hw), l = bits_h2(lw);
+                        e.v[x0] = mix_add(l[0], mix_add(h[0], e.v[x0], one), one);
+                        e.v[x0 + 1] = mix_add(l[1], mix_add(h[1], e.v[x0 + 1], one), one);
+                    } else if constexpr (KIND == 1) {
+                        // leaky_relu(v, 0.01) = max(v, 0.01 v) = med3(v, 0.01 v, huge)
+                        e.v[x0] = __builtin_amdgcn_fmed3f(e.v[x0], 0.01f * e.v[x0], 3.0e38f);
+                        e.v[x0 + 1] = __builtin_amdgcn_fmed3f(e.v[x0 + 1], 0.01f * e.v[x0 + 1], 3.0e38f);
+                    } else if constexpr (KIND == 3) {
+                        const float4 sv = ysv[n & 1][m];
+                        const float s0 = pr == 0 ? sv.x : sv.z, s1 = pr == 0 ? sv.y : sv.w;
+                        e.v[x0] = s0 > 0.f ? e.v[x0] : 0.01f * e.v[x0];
+                        e.v[x0 + 1] = s1 > 0.f ? e.v[x0 + 1] : 0.01f * e.v[x0 + 1];
+                    }
+                }
+            } else if (k == 4 || k == 5) {
+                const int m = k - 4;
+                if constexpr (DUMP) st4(dlane + n * dstep + 4 * m, make_float4(e.v[4 * m], e.v[4 * m + 1], e.v[4 * m + 2], e.v[4 * m + 3]));
+                const half2v h01 = cvt_h2(e.v[4 * m], e.v[4 * m + 1]), h23 = cvt_h2(e.v[4 * m + 2], e.v[4 * m + 3]);
+                const float r0 = mix_sub(h01[0], e.v[4 * m], one), r1 = mix_sub(h01[1], e.v[4 * m + 1], one);
+                const float r2 = mix_sub(h23[0], e.v[4 * m + 2], one), r3 = mix_sub(h23[1], e.v[4 * m + 3], one);
+                e.hi[2 * m] = h2_bits(h01); e.hi[2 * m + 1] = h2_bits(h23);
+                e.lo[2 * m] = h2_bits(cvt_h2(r0, r1)); e.lo[2 * m + 1] = h2_bits(cvt_h2(r2, r3));
+            } else {
+                *reinterpret_cast<uint4*>(dst + e.slot) = make_uint4(e.hi[0], e.hi[1], e.hi[2], e.hi[3]);
+                *reinterpret_cast<uint4*>(dst + e.slot + 128) = make_uint4(e.lo[0], e.lo[1], e.lo[2], e.lo[3]);
+            }
+        };
+        const int cthis = (j - 1) * BODY_CHUNKS_K7;
+        const int cnext = (j * BODY_CHUNKS_K7) % NCHUNK_STEP;          // the layer after the step's last one is the next step's first
+        Epi ep[2];
+        uint4 bq[NB][2];
+#pragma unroll
+        for (int g = 0; g < PD; ++g) bload(bq[g % NB], g / HC, g % HC);
+        STAMP_ADD(3);                             // layer set-up
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+#pragma unroll
+                for (int c = 0; c < HC; ++c) {
+                    const int g = (ps * NN + n) * HC + c;              // position in the layer's sequence of 84 (tile, chunk) units
+                    if (g + PD < 2 * NN * HC) {
+                        const int g2 = g + PD;
+                        bload(bq[g2 % NB], (g2 / HC) % NN, (g2 / (NN * HC)) * HC + g2 % HC);
+                    }
+                    if (BWD && KIND == 3 && ps == 1 && c == 0) ys_load(n);
+                    const uint4 (&b)[2] = bq[g % NB];
+                    const uint4 (&w)[FRAGS_PER_CHUNK] = W[ps][c];
+                    floatx4 (&a)[2] = acc[n];
+                    const bool first = ps == 0 && c == 0;            // the layer's bias enters as the C operand of the first MFMA
+                    a[0] = mfma16(w[0], b[0], first ? bvec[0] : a[0]);
+                    a[1] = mfma16(w[2], b[0], first ? bvec[1] : a[1]);
+                    a[0] = mfma16(w[0], b[1], a[0]);
+                    a[1] = mfma16(w[2], b[1], a[1]);
+                    a[0] = mfma16(w[1], b[0], a[0]);
+                    a[1] = mfma16(w[3], b[0], a[1]);
+                    // the other half's weights, one chunk per tile (the last tile: two), a whole pass ahead of their use
+                    if (c == 3 || (n == NN - 1 && c == 1)) {
+                        const int cw = (c == 3) ? n : HC - 1;
+                        const int csrc = ps == 0 ? cthis + HC + cw : cnext + cw;
+#pragma unroll
+                        for (int f = 0; f < FRAGS_PER_CHUNK; ++f) W[ps ^ 1][cw][f] = wload(csrc, f);
+                    }
+                    if (ps == 1 && n > 0) piece(ep[(n - 1) & 1], n - 1, c);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+                    __builtin_amdgcn_sched_barrier(0);     // one scheduling region per unit: prefetches stay where they are written
+                }
+            }
+        }
+        STAMP_ADD(4);                             // both passes incl. the overlapped epilogues
+#pragma unroll
+        for (int k = 0; k < HC; ++k) piece(ep[(NN - 1) & 1], NN - 1, k);
+        // Rows outside [0, L) of their waveform (gap rows, stream ends, segment padding) must read as zeros for the next layer
+        // (= its zero padding): the lanes of padding rows overwrite what the branch-free pieces stored (same lane, program
+        // order: no race; the barrier follows), and the training dump takes the valid rows of the span from the LDS image.
+        if (!span_ok) {
+#pragma unroll 1
+            for (int n = 0; n < NN; ++n) {
+                bool valid;
+                int slot, nw, tw, tk;
+                row_of(n, valid, slot, nw, tw, tk);
+                if (!valid) {
+                    *reinterpret_cast<uint4*>(dst + slot) = make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(dst + slot + 128) = make_uint4(0u, 0u, 0u, 0u);
+                } else if (DUMP && tk >= p.halo && tk < p.halo + p.seg_len) {
+                    const half8 hh8 = as_h8(ldq(dst + slot)), ll8 = as_h8(ldq(dst + slot + 128));
+                    float* const o = dumpj + ((size_t)nw * Ltrue + tw) * NF + 32 * mi + 8 * q4;
+                    st4(o, make_float4((float)hh8[0] + (float)ll8[0], (float)hh8[1] + (float)ll8[1],
+                                       (float)hh8[2] + (float)ll8[2], (float)hh8[3] + (float)ll8[3]));
+                    st4(o + 4, make_float4((float)hh8[4] + (float)ll8[4], (float)hh8[5] + (float)ll8[5],
+                                           (float)hh8[6] + (float)ll8[6], (float)hh8[7] + (float)ll8[7]));
+                }
+            }
+        }
+        STAMP_ADD(5);                             // exposed epilogue (last tile) + padding fix-up
+        __syncthreads();
+        STAMP_ADD(2);
+    };
+
+    // conv_last with r <= 16: one 16-channel output tile on v_mfma_f32_16x16x32_f16, every wave 48 rows of the step (as r3)
+    auto conv_last16 = [&]() {
+        int nR = nS, tR = tS - LAG_LAST;
+        while (tR < 0) { tR += Lp; nR -= 1; }
+        const char* const src = Yr;               // sweep layer 12 reads conv12's output
+        const int R0 = F - S - LAG_LAST;
+        const int j16 = lane & 15;
+        const uint4* lw = reinterpret_cast<const uint4*>(p.last16) + lane;
+        uint4 wh[BODY_CHUNKS_LAST], wl[BODY_CHUNKS_LAST];
+#pragma unroll
+        for (int cc = 0; cc < BODY_CHUNKS_LAST; ++cc) { wh[cc] = lw[(cc * 2) * 64]; wl[cc] = lw[(cc * 2 + 1) * 64]; }
+        const float4 b4 = ld4(biasl + 12 * 64 + 4 * q4);
+        floatx4 a16[3];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a16[k][0] = b4.x; a16[k][1] = b4.y; a16[k][2] = b4.z; a16[k][3] = b4.w;
+            const int off = 48 * wave + 16 * k + j16;
+#pragma unroll
+            for (int cc = 0; cc < BODY_CHUNKS_LAST; ++cc) {
+                const int d = cc >> 1, hh = cc & 1;
+                const char* row = src + ((R0 + off + d - 1) & (RING - 1)) * ROWB + (32 * hh + 8 * q4) * 2;
+                const half8 bh = as_h8(ldq(row)), bl = as_h8(ldq(row + 128));
+                a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wh[cc]), bh, a16[k], 0, 0, 0);
+                a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wh[cc]), bl, a16[k], 0, 0, 0);
+                a16[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wl[cc]), bh, a16[k], 0, 0, 0);
+            }
+        }
+        STAMP_ADD(4);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int off = 48 * wave + 16 * k + j16;
+            const int g = R0 + off;
+            int nk, tk, nw, tw;
+            decode_row(nR, tR, off, nk, tk);
+            vmap(n0 + nk, tk, nw, tw);
+            const bool ok = (g >= 0) && (g < gend) && (tk < L) && (tw >= 0) && (tw < Ltrue) &&
+                            (tk >= p.halo) && (tk < p.halo + p.seg_len);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad = bad || !(fabsf(a16[k][e]) <= 3.0e38f);
+            if (p.onset_ws != nullptr) {
+                // fused arg-max picker: per (virtual) waveform of this tile -- at most two, the tile is 16 consecutive stream
+                // rows -- its max / min and the positions equal to the max
+                const bool lane_ok = ok && 4 * q4 < r;
+                float lm = -INFINITY, ll = INFINITY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (lane_ok && 4 * q4 + e < r) { lm = fmaxf(lm, a16[k][e]); ll = fminf(ll, a16[k][e]); }
+                const int nv = n0 + nk;
+                const int nvA = __shfl(nv, 0), nvB = __shfl(nv, 15);
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int nvX = pass ? nvB : nvA;
+                    if (pass && nvB == nvA) break;
+                    const bool mine = lane_ok && nv == nvX;
+                    const unsigned long long mm = __ballot(mine) & 0xffffull;
+                    if (mm == 0) continue;
+                    float m = mine ? lm : -INFINITY, lo = mine ? ll : INFINITY;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); lo = fminf(lo, __shfl_xor(lo, o)); }
+                    const int jf = __builtin_ctzll(mm);
+                    const int tw_base = __shfl(tw - j16, jf);
+                    const int nwX = __shfl(nw, jf);
+                    const int seg = nvX & seg_mask;
+                    const int slot = seg * p.onset_seg_slots + (tw_base + jf - seg * p.seg_len + 15) / 16;
+                    unsigned long long eq[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) eq[e] = __ballot(mine && 4 * q4 + e < r && a16[k][e] == m);
+                    if (lane == 0) {
+                        uint4* d4 = reinterpret_cast<uint4*>(p.onset_ws + (size_t)nwX * p.onset_slots + slot);
+                        d4[0] = make_uint4(1u, (unsigned)tw_base, __float_as_uint(m), __float_as_uint(lo));
+                        d4[1] = make_uint4((unsigned)eq[0], (unsigned)(eq[0] >> 32), (unsigned)eq[1], (unsigned)(eq[1] >> 32));
+                        d4[2] = make_uint4((unsigned)eq[2], (unsigned)(eq[2] >> 32), (unsigned)eq[3], (unsigned)(eq[3] >> 32));
+                    }
+                }
+            }
+            if (!ok || 4 * q4 >= r || p.y == nullptr) continue;
+            float* const orow = p.y + ((size_t)nw * Ltrue + tw) * r + 4 * q4;
+            if ((r & 3) == 0) {
+                st4(orow, make_float4(a16[k][0], a16[k][1], a16[k][2], a16[k][3]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q4 + e < r) orow[e] = a16[k][e];
+            }
+        }
+        if (p.status != nullptr && __any(bad) && lane == 0) atomicOr(p.status, 1);
+        STAMP_ADD(5);
+        __syncthreads();
+        STAMP_ADD(2);
+    };
+
+    // conv_last with r > 16 (64-wide output block, of which r channels are real): tile-major on the wave's six N-tiles, its
+    // 6 chunks in weight buffer 1 (free: conv12's pass B is over; buffer 0 already holds the next step's first half-layer)
+    auto conv_last_wide = [&]() {
+        int nR = nS, tR = tS - LAG_LAST;
+        while (tR < 0) { tR += Lp; nR -= 1; }
+        const char* const src = Yr;
+        const int R0 = F - S - LAG_LAST;
+#pragma unroll
+        for (int cc = 0; cc < BODY_CHUNKS_LAST; ++cc)
+#pragma unroll
+            for (int f = 0; f < FRAGS_PER_CHUNK; ++f) W[1][cc][f] = wload(NCHUNK_STEP + cc, f);
+        floatx4 bvec[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float4 bb = ld4(biasl + 12 * 64 + 32 * mi + 8 * q4 + 4 * m);
+            bvec[m][0] = bb.x; bvec[m][1] = bb.y; bvec[m][2] = bb.z; bvec[m][3] = bb.w;
+        }
+        const int rbase = R0 + 16 * NN * ni + i16 - 1;
+        bool bad = false;
+#pragma unroll 1
+        for (int n = 0; n < NN; ++n) {
+            uint4 b[BODY_CHUNKS_LAST][2];
+#pragma unroll
+            for (int cc = 0; cc < BODY_CHUNKS_LAST; ++cc) {
+                const char* row = src + ((rbase + 16 * n + (cc >> 1)) & (RING - 1)) * ROWB + 64 * (cc & 1) + 16 * q4;
+                b[cc][0] = ldq(row);
+                b[cc][1] = ldq(row + 128);
+            }
+            floatx4 a[2] = {bvec[0], bvec[1]};
+#pragma unroll
+            for (int cc = 0; cc < BODY_CHUNKS_LAST; ++cc) {
+                const uint4 (&w)[FRAGS_PER_CHUNK] = W[1][cc];
+                a[0] = mfma16(w[0], b[cc][0], a[0]);
+                a[1] = mfma16(w[2], b[cc][0], a[1]);
+                a[0] = mfma16(w[0], b[cc][1], a[0]);
+                a[1] = mfma16(w[2], b[cc][1], a[1]);
+                a[0] = mfma16(w[1], b[cc][0], a[0]);
+                a[1] = mfma16(w[3], b[cc][0], a[1]);
+            }
+            const int off = 16 * (NN * ni + n) + i16;
+            const int g = R0 + off;
+            int nk, tk, nw, tw;
+            decode_row(nR, tR, off, nk, tk);
+            vmap(n0 + nk, tk, nw, tw);
+            // conv_last + SampleShuffle1D: out[n][t*r + k] = conv_last[n][k][t]; only the segment's own rows
+            const bool valid = (g >= 0) && (g < gend) && (tk < L) && (tw >= 0) && (tw < Ltrue) && (tk >= p.halo) && (tk < p.halo + p.seg_len);
+            const float v[8] = {a[0][0], a[0][1], a[0][2], a[0][3], a[1][0], a[1][1], a[1][2], a[1][3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bad = bad || !(fabsf(v[e]) <= 3.0e38f);
+            if (!valid || p.y == nullptr) continue;
+            float* const orow = p.y + ((size_t)nw * Ltrue + tw) * r;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int c0 = 32 * mi + 8 * q4 + 4 * m;
+                if (c0 >= r) continue;
+                if ((r & 3) == 0) {
+                    st4(orow + c0, make_float4(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c0 + e < r) orow[c0 + e] = v[4 * m + e];
+                }
+            }
+        }
+        if (p.status != nullptr && __any(bad) && lane == 0) atomicOr(p.status, 1);
+        STAMP_ADD(5);
+        __syncthreads();
+        STAMP_ADD(2);
+    };
+
+    for (int step = 1; step <= nsteps; ++step) {
+        F = step * S;
+        if (step > 1) {
+            tS += S;
+            while (tS >= Lp) { tS -= Lp; nS += 1; }
+        }
+        // land the raw samples [F+4-S, F+4) and the SemiGlobalBlock rows fetched one step ago, start the next step's fetch
+        if constexpr (!BWD) {
+            if (tid < S) rawr[(F + 4 - S + tid) & (RAWRING - 1)] = raw_next;
+            if (sg_slot >= 0) sgl[sg_slot * NF + (tid & 63)] = sg_next;
+            int nN = nS, tN = tS + S;
+            while (tN >= Lp) { tN -= Lp; nN += 1; }
+            fetch_step(F + S, nN, tN);
+        }
+        __syncthreads();
+        STAMP_ADD(0);
+        if constexpr (BWD) gin_pass(Xr, F - S, nS, tS);
+        else x0_pass(Xr, F - S, nS, tS, true);    // sweep layer 0
+        STAMP_ADD(1);
+        __syncthreads();
+        STAMP_ADD(2);
+        if constexpr (!BWD) {
+            // conv2 .. conv11: (leaky ReLU, residual add) x 5; then the long skip seeds ring Y with x0 and conv12 adds in place
+#pragma unroll 1
+            for (int pp = 0; pp < 5; ++pp) {
+                layer(std::integral_constant<int, 1>{}, 2 * pp + 1);
+                layer(std::integral_constant<int, 0>{}, 2 * pp + 2);
+            }
+            {
+                int nR = nS, tR = tS - 33;
+                while (tR < 0) { tR += Lp; nR -= 1; }
+                x0_pass(Yr, F - S - 33, nR, tR, false);
+                STAMP_ADD(1);
+                __syncthreads();
+                STAMP_ADD(2);
+            }
+            layer(std::integral_constant<int, 0>{}, 11);
+            if (p.last16 != nullptr) conv_last16();
+            else conv_last_wide();
+        } else {
+            // conv12^T plain, then (conv(2k+3)^T times lrelu'(saved), conv(2k+2)^T added in place) x 5
+            layer(std::integral_constant<int, 2>{}, 1);
+#pragma unroll 1
+            for (int pp = 0; pp < 5; ++pp) {
+                layer(std::integral_constant<int, 3>{}, 2 * pp + 2);
+                layer(std::integral_constant<int, 0>{}, 2 * pp + 3);
+            }
+        }
+    }
+#ifdef STOF_STAMPS
+    if (lane == 0 && p.stamps) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = tsum[i];
+        o[6] = stamp() - tstart;
+        o[7] = (unsigned long long)nsteps;
+    }
+#endif
+}

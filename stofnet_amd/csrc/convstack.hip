@@ -1297,6 +1297,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
 #endif
 }
 
+#include "body_p2.h"      // round 4: the split-fp16 sweep with two-pass tile-major k7 layers (the default)
+
 // ----------------------------------------------------------------------------------
 // SemiGlobalBlock contracting path: relu(conv1) -> conv 64->512 k5 -> lrelu -> maxpool 80
 // One work-group = NW pooling windows of one waveform.  Time sits on the MFMA M axis so
@@ -1669,12 +1671,17 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
 
     // split-fp16 body: 16x16x32 MFMA form unless STOF_BODY16=0 (the packed blob carries the matching fragment order)
     static const bool body16 = PREC == STOF_PREC_F16X3 && body16_enabled();
+    // r4: two-pass tile-major layers (body_p2.h) unless STOF_BODY_P2=0 (the r3 chunk-major kernel, kept for A/B runs)
+    static const bool body_p2 = body16 && body_p2_enabled();
     constexpr int SHAPE_FAST = PREC == STOF_PREC_F16X3 ? 16 : 32;
     using Lds = BodyLds<BODY_S, BODY_RING, BODY_RAWRING>;
     using Lds16 = BodyLds<BODY_S, BODY_RING, BODY_RAWRING, ROWF16>;
     const size_t body_lds_bytes = body16 ? Lds16::BYTES : Lds::BYTES;
-    static LdsLimitOnce body_lds, body16_lds, sgb_lds;     // one per template instantiation (PREC)
-    if (body16) {
+    static LdsLimitOnce body_lds, body16_lds, body_p2_lds, sgb_lds;     // one per template instantiation (PREC)
+    if (body_p2) {
+        if (int st = body_p2_lds.ensure(reinterpret_cast<const void*>(&body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING>),
+                                        (int)Lds16::BYTES)) return st;
+    } else if (body16) {
         if (int st = body16_lds.ensure(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING, SHAPE_FAST>),
                                        (int)Lds16::BYTES)) return st;
     } else if (int st = body_lds.ensure(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>),
@@ -1771,7 +1778,10 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         int64_t wgs = nv < ncu ? nv : ncu;
         bp.wf_per_wg = (int)((nv + wgs - 1) / wgs);
         wgs = (nv + bp.wf_per_wg - 1) / bp.wf_per_wg;
-        if (body16)
+        if (body_p2)
+            hipLaunchKernelGGL((body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING>), dim3((unsigned)wgs), dim3(256),
+                               body_lds_bytes, stream, bp);
+        else if (body16)
             hipLaunchKernelGGL((body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING, SHAPE_FAST>), dim3((unsigned)wgs), dim3(256),
                                body_lds_bytes, stream, bp);
         else
@@ -2025,7 +2035,9 @@ extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev,
     if ((L + GAP) * N > 0x7fffffffLL || N * L * NF > 0x7fffffffffLL) return STOF_ERR_UNSUPPORTED;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using Lds16 = BodyLds<BODY_S, BODY_RING, BODY_RAWRING, ROWF16>;
-    auto kernel = &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, false>;
+    static const bool p2 = body_p2_enabled();
+    auto kernel = p2 ? &body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING, true, false>
+                     : &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, false>;
     static LdsLimitOnce lds;
     if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)Lds16::BYTES)) return st;
     const float* base = static_cast<const float*>(blob_dev);
@@ -2150,7 +2162,9 @@ extern "C" int stof_train_sweep_bwd(const stof_net_desc* desc, const void* blob_
     if ((L + GAP) * N > 0x7fffffffLL || N * L * NF > 0x7fffffffffLL) return STOF_ERR_UNSUPPORTED;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using Lds16 = BodyLds<BODY_S, BODY_RING, BODY_RAWRING, ROWF16>;
-    auto kernel = &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, true>;
+    static const bool p2 = body_p2_enabled();
+    auto kernel = p2 ? &body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING, true, true>
+                     : &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, true>;
     static LdsLimitOnce lds;
     if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)Lds16::BYTES)) return st;
     const float* base = static_cast<const float*>(blob_dev);

@@ -73,6 +73,12 @@ inline bool body16_enabled() {
     const char* e = getenv("STOF_BODY16");
     return e == nullptr || e[0] != '0';
 }
+// r4: the 16x16x32 body sweeps its k7 layers two-pass tile-major (body_p2.h); STOF_BODY_P2=0 selects the r3 chunk-major kernel
+// on the same packed blob (A/B runs)
+inline bool body_p2_enabled() {
+    const char* e = getenv("STOF_BODY_P2");
+    return e == nullptr || e[0] != '0';
+}
 constexpr int LAST16_F = 6 * 2 * 64 * 4;      // floats of the off_last16 section
 
 }  // namespace stof
