@@ -18,6 +18,21 @@
 //  * the kinds of a step's layers alternate (leaky ReLU, residual add), so the step runs them as straight-line PAIRS: a branch
 //    between two 500-MFMA bodies that both redefine 224 weight registers made the compiler reconcile them with ~120 moves
 //    and a vmcnt(0) at every layer end.
+// LDS accesses of the hand-placed stream by 32-bit LDS address: through generic pointers hipcc did the ring-row arithmetic
+// in 64 bits (v_mad_u64_u32 + moves) once the values were pinned.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4_t lds_cu4_t;
+typedef __attribute__((address_space(3))) u32x4_t lds_u4_t;
+typedef __attribute__((address_space(3))) char lds_char_t;
+__device__ __forceinline__ uint4 lds_ldq(unsigned a) {
+    const u32x4_t v = *(lds_cu4_t*)(a);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void lds_stq(unsigned a, uint4 v) {
+    const u32x4_t w = {v.x, v.y, v.z, v.w};
+    *(lds_u4_t*)(a) = w;
+}
+
 template <int S, int RING, int RAWRING, bool DUMP = false, bool BWD = false>
 __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams p) {
     constexpr int PREC = STOF_PREC_F16X3;
@@ -112,8 +127,9 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                 if (dump0 != nullptr)
                     st4(dump0 + ((size_t)(n0 + nR) * Ltrue + tR + rl * NIT + it) * NF + 4 * cq, make_float4(v[0], v[1], v[2], v[3]));
                 const half2v h01 = cvt_h2(v[0], v[1]), h23 = cvt_h2(v[2], v[3]);
-                const half2v l01 = cvt_h2(mix_sub(h01[0], v[0], one_x0), mix_sub(h01[1], v[1], one_x0));
-                const half2v l23 = cvt_h2(mix_sub(h23[0], v[2], one_x0), mix_sub(h23[1], v[3], one_x0));
+                half2v l01, l23;                    // v - hi is exact in fp32: one rounding to fp16 (v_fma_mixlo_f16 / mixhi)
+                l01[0] = (_Float16)mix_sub(h01[0], v[0], one_x0); l01[1] = (_Float16)mix_sub(h01[1], v[1], one_x0);
+                l23[0] = (_Float16)mix_sub(h23[0], v[2], one_x0); l23[1] = (_Float16)mix_sub(h23[1], v[3], one_x0);
                 *reinterpret_cast<uint2*>(row + 8 * cq) = make_uint2(h2_bits(h01), h2_bits(h23));
                 *reinterpret_cast<uint2*>(row + 128 + 8 * cq) = make_uint2(h2_bits(l01), h2_bits(l23));
             }
@@ -215,8 +231,16 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
 
     // ---- weights: two half-layer buffers of 7 chunks x 4 fragments (M-tile 0 hi | lo, M-tile 1 hi | lo), see the header
     constexpr int HC = BODY_CHUNKS_K7 / 2;
-    const uint4* const wbase = reinterpret_cast<const uint4*>(p.chunks) + mi * 64 + lane;
-    auto wload = [&](int c, int f) -> uint4 { return wbase[((size_t)c * FRAGS_PER_CHUNK + f) * 128]; };
+    // fragment f of chunk c for this wave's 32-channel block, as a raw buffer load: resource = the chunk blob (scalar registers),
+    // vector offset = 16 lane, scalar offset = the fragment's byte offset -- no vector address arithmetic and one s_add per load
+    // (with flat 64-bit lane addresses hipcc hoisted 28 addresses per pass out of the step loop, spilled them and reloaded each
+    // behind vmcnt(0); computed in place they cost a 64-bit VALU add per load)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.chunks), 0, 0x7fffffff, 0x00020000);
+    const int woff = lane * 16;
+    auto wload = [&](int c, int f) -> uint4 {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff, (c * FRAGS_PER_CHUNK + f) * 2048 + mi * 1024, 0);
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    };
     uint4 W[2][HC][FRAGS_PER_CHUNK];
 #pragma unroll
     for (int c = 0; c < HC; ++c)
@@ -241,7 +265,19 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
     int nS = 0, tS = 0;                           // waveform / time of stream row F - S (wave-uniform)
     int F = 0;
 
-    // One k7 layer.  KIND: 0 = residual add in place, 1 = leaky ReLU (forward), 2 = plain, 3 = times lrelu'(saved) (backward)
+    // One k7 layer.  KIND: 0 = residual add in place, 1 = leaky ReLU (forward), 2 = plain, 3 = times lrelu'(saved) (backward).
+    //
+    // The instruction stream is placed BY HAND: a unit = one (N-tile, chunk) = 6 MFMAs, and behind every MFMA sit at most two
+    // single-issue instructions (free beside a 16x16x32 MFMA; a third costs its whole issue time: tools/micro/gen_issue_cost.py,
+    // profiles/r04_issue_cost.jsonl), closed by a scheduling barrier so the compiler keeps them there -- left to the
+    // sched_group_barrier solver the epilogue's VALU clumped in groups of 8 between MFMAs and pass B ran at 22.7 cycles per MFMA.
+    //   gap 0: ds_read hi fragment of the unit PD ahead | E        gap 3: E, A
+    //   gap 1: ds_read lo fragment                      | E        gap 4: E, A
+    //   gap 2: E, E                                                gap 5: A, G
+    // (scalar instructions and s_waitcnt take the same issue slots as vector ones: two per gap in all)
+    // E = the next instruction of the previous tile's epilogue queue (pass B; 42 slots per tile for its <= 41 instructions),
+    // A = the three instructions of the LDS address of the unit PD + 1 ahead when its tap changes, G = one weight-fragment load
+    // for the other half-layer buffer (28 per pass).
     auto layer = [&](auto kind_c, const int j) {
         constexpr int KIND = decltype(kind_c)::value;
         constexpr bool INPL = KIND == 0;
@@ -256,14 +292,6 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
             const float4 bb = ld4(biasl + j * 64 + 32 * mi + 8 * q4 + 4 * m);
             bvec[m][0] = bb.x; bvec[m][1] = bb.y; bvec[m][2] = bb.z; bvec[m][3] = bb.w;
         }
-        const int rbase = R0 + 16 * NN * ni + i16 - 3;          // row of N-tile 0, tap 0
-        const int cbyte = 16 * q4;
-        auto bload = [&](uint4 (&b)[2], int n, int cc) {
-            const int d = cc >> 1, hh = cc & 1;
-            const char* row = src + ((rbase + 16 * n + d) & (RING - 1)) * ROWB + 64 * hh + cbyte;
-            b[0] = ldq(row);
-            b[1] = ldq(row + 128);
-        };
         auto row_of = [&](int n, bool& valid, int& slot, int& nw, int& tw, int& tk) {
             const int off = 16 * (NN * ni + n) + i16;
             const int g = R0 + off;
@@ -292,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
             }
         }
         // backward, masked layers: saved activation of the lane's 8 channels of its row of N-tile n (the forward dump's tensor
-        // 1 + 2 k, k = 5 - j/2), requested one tile before the piece that uses it
+        // 1 + 2 k, k = 5 - j/2), requested one tile before the epilogue that uses it
         const float* const ysp = (BWD && KIND == 3) ? p.fwd_dump + (size_t)(1 + 2 * (5 - (j >> 1))) * p.dump_stride + 32 * mi + 8 * q4 : nullptr;
         float4 ysv[2][2];
         auto ys_load = [&](int n) {
@@ -313,105 +341,153 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                 }
             }
         };
-        // The epilogue of N-tile n (8 consecutive channels of one row per lane) in seven pieces of <= 8 VALU instructions, piece k
-        // behind chunk k of the NEXT tile's pass B.  Branch-free; rows that are padding are zeroed after the layer (rare).
-        struct Epi { int slot; uint4 oh, ol; float v[8]; unsigned hi[4], lo[4]; };
+
+        // ---- activation fragments: unit g = (pass ps, tile n, chunk c) reads rows rbase + 16 n + d of src, d = tap of chunk
+        // cc = 7 ps + c, at byte 64 (cc & 1) (+ 128: lo) of the lane's 16-byte column.  `aq` = LDS byte address of (tile, tap).
+        const unsigned lds_base = (unsigned)(size_t)(lds_char_t*)smem;
+        const unsigned src_a = lds_base + ((j & 1) ? Lds::X : Lds::Y) * 4, dst_a = lds_base + ((j & 1) ? Lds::Y : Lds::X) * 4;
+        const int rbase = R0 + 16 * NN * ni + i16 - 3;          // row of N-tile 0, tap 0
+        const unsigned asrc = src_a + 16 * q4;
+        const unsigned slotdelta = dst_a - src_a + 64 * mi;     // from the (tile, tap 3) operand address to the epilogue's slot in dst
+        unsigned at = 0, aq = 0;
+        auto unit_cc = [](int g) { return (g / (NN * HC)) * HC + g % HC; };
+        auto unit_tile = [](int g) { return (g / HC) % NN; };
+        auto new_tap = [&](int g) { return g % HC == 0 || (unit_cc(g) & 1) == 0; };
+        // PIN(x): an empty volatile asm that 'rewrites' x.  Pure arithmetic floats freely in the compiler's DAG (it is linearised
+        // right in front of its first user, and only then do the scheduling barriers freeze the order): the pin is a user that
+        // sits where the instruction is wanted.  Never on a load's result: the pin would be a wait for it.
+#define STOF_PIN(x) asm volatile("" : "+v"(x))
+        auto addr_op = [&](int g, int k) {                       // instruction k of the address of unit g
+            if (k == 0) { at = (unsigned)(rbase + (16 * unit_tile(g) + (unit_cc(g) >> 1))); STOF_PIN(at); }
+            else if (k == 1) { at = at & (RING - 1); STOF_PIN(at); }
+            else { aq = __umul24(at, ROWB) + asrc; STOF_PIN(aq); }
+        };
+        auto frag_read = [&](uint4& b, int g, int part) { b = lds_ldq(aq + 64 * (unit_cc(g) & 1) + 128 * part); };
+
+        // ---- epilogue of N-tile t (8 consecutive channels of one row per lane) as a queue of single instructions
+        struct Epi { uint4 oh, ol; float v[8], w[8]; unsigned h[4], l[4]; };
         floatx4 acc[NN][2];
-        auto piece = [&](Epi& e, int n, int k) {
-            if (k == 0) {
-                e.slot = ((R0 + 16 * (NN * ni + n) + i16) & (RING - 1)) * ROWB + (32 * mi + 8 * q4) * 2;
-                if constexpr (INPL) { e.oh = ldq(dst + e.slot); e.ol = ldq(dst + e.slot + 128); }
-            } else if (k == 1) {
-#pragma unroll
-                for (int x = 0; x < 8; ++x) e.v[x] = acc[n][x >> 2][x & 3];
-            } else if (k == 2 || k == 3) {
-                const int m = k - 2;
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int x0 = 4 * m + 2 * pr;
-                    if constexpr (INPL) {
-                        const unsigned hw = m ? (pr == 0 ? e.oh.z : e.oh.w) : (pr == 0 ? e.oh.x : e.oh.y);
-                        const unsigned lw = m ? (pr == 0 ? e.ol.z : e.ol.w) : (pr == 0 ? e.ol.x : e.ol.y);
-                        const half2v h = bits_h2(hw), l = bits_h2(lw);
-                        e.v[x0] = mix_add(l[0], mix_add(h[0], e.v[x0], one), one);
-                        e.v[x0 + 1] = mix_add(l[1], mix_add(h[1], e.v[x0 + 1], one), one);
-                    } else if constexpr (KIND == 1) {
-                        // leaky_relu(v, 0.01) = max(v, 0.01 v) = med3(v, 0.01 v, huge)
-                        e.v[x0] = __builtin_amdgcn_fmed3f(e.v[x0], 0.01f * e.v[x0], 3.0e38f);
-                        e.v[x0 + 1] = __builtin_amdgcn_fmed3f(e.v[x0 + 1], 0.01f * e.v[x0 + 1], 3.0e38f);
-                    } else if constexpr (KIND == 3) {
-                        const float4 sv = ysv[n & 1][m];
-                        const float s0 = pr == 0 ? sv.x : sv.z, s1 = pr == 0 ? sv.y : sv.w;
-                        e.v[x0] = s0 > 0.f ? e.v[x0] : 0.01f * e.v[x0];
-                        e.v[x0 + 1] = s1 > 0.f ? e.v[x0 + 1] : 0.01f * e.v[x0 + 1];
+        unsigned slotq[3];                                            // LDS byte address of the lane's 16 bytes of its row of tile t (hi image); tile t's
+                                                                 // is taken two units before pass-B tile t starts and used until tile t + 1 ends
+        // instruction q (0..41) of the queue that runs behind the MFMAs of pass-B tile t + 1 (or exposed, for the last tile)
+        auto epi_op = [&](Epi& e, int t, int q) {
+            const unsigned sl = slotq[t % 3];
+            if (q < 2) {
+                if constexpr (INPL) { if (q == 0) e.oh = lds_ldq(sl); else e.ol = lds_ldq(sl + 128); }
+            } else if (q < 10) {
+                const int x = q - 2;
+                e.v[x] = acc[t][x >> 2][x & 3];
+                STOF_PIN(e.v[x]);
+            } else if (q < 26) {
+                const int k = q - 10;
+                if constexpr (INPL) {                            // + old hi (k < 8), + old lo (k >= 8): value x of pair x >> 1
+                    const int x = k & 7, pr = x >> 1;
+                    const uint4& o = k < 8 ? e.oh : e.ol;
+                    const half2v hv = bits_h2(pr == 0 ? o.x : pr == 1 ? o.y : pr == 2 ? o.z : o.w);
+                    e.v[x] = mix_add(hv[x & 1], e.v[x], one);
+                    STOF_PIN(e.v[x]);
+                } else if constexpr (KIND == 1) {                // leaky_relu(v, 0.01) = med3(v, 0.01 v, huge): 8 v_mul, then 8 v_med3
+                    const int x = k & 7;                          // (a dependent pair back to back stalls the wave for the VALU latency)
+                    if (k < 8) { e.w[x] = 0.01f * e.v[x]; STOF_PIN(e.w[x]); }
+                    else { e.v[x] = __builtin_amdgcn_fmed3f(e.v[x], e.w[x], 3.0e38f); STOF_PIN(e.v[x]); }
+                } else if constexpr (KIND == 3) {                // times lrelu'(saved activation): one value per slot
+                    if (k < 8) {
+                        const float4 sv = ysv[t & 1][k >> 2];
+                        const float sx = (k & 3) == 0 ? sv.x : (k & 3) == 1 ? sv.y : (k & 3) == 2 ? sv.z : sv.w;
+                        e.v[k] = sx > 0.f ? e.v[k] : 0.01f * e.v[k];
+                        STOF_PIN(e.v[k]);
                     }
                 }
-            } else if (k == 4 || k == 5) {
-                const int m = k - 4;
-                if constexpr (DUMP) st4(dlane + n * dstep + 4 * m, make_float4(e.v[4 * m], e.v[4 * m + 1], e.v[4 * m + 2], e.v[4 * m + 3]));
-                const half2v h01 = cvt_h2(e.v[4 * m], e.v[4 * m + 1]), h23 = cvt_h2(e.v[4 * m + 2], e.v[4 * m + 3]);
-                const float r0 = mix_sub(h01[0], e.v[4 * m], one), r1 = mix_sub(h01[1], e.v[4 * m + 1], one);
-                const float r2 = mix_sub(h23[0], e.v[4 * m + 2], one), r3 = mix_sub(h23[1], e.v[4 * m + 3], one);
-                e.hi[2 * m] = h2_bits(h01); e.hi[2 * m + 1] = h2_bits(h23);
-                e.lo[2 * m] = h2_bits(cvt_h2(r0, r1)); e.lo[2 * m + 1] = h2_bits(cvt_h2(r2, r3));
-            } else {
-                *reinterpret_cast<uint4*>(dst + e.slot) = make_uint4(e.hi[0], e.hi[1], e.hi[2], e.hi[3]);
-                *reinterpret_cast<uint4*>(dst + e.slot + 128) = make_uint4(e.lo[0], e.lo[1], e.lo[2], e.lo[3]);
+            } else if (q < 30) {
+                const int pr = q - 26;
+                e.h[pr] = h2_bits(cvt_h2(e.v[2 * pr], e.v[2 * pr + 1]));
+                STOF_PIN(e.h[pr]);
+            } else if (q == 30) {
+                // (slot of the tile after next: see the call sites; nothing of this tile)
+            } else if (q < 39) {
+                // lo = fp16(v - hi): v_fma_mixlo_f16 / v_fma_mixhi_f16 (the difference is exact in fp32, so the one rounding equals
+                // cvt(fma)); the four low halves first, then the four high halves: mixhi reads the register its mixlo wrote
+                const int k = q - 31, pr = k & 3;
+                if (k < 4) asm volatile("v_fma_mixlo_f16 %0, -%1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(e.l[pr]) : "v"(e.h[pr]), "s"(one), "v"(e.v[2 * pr]));
+                else asm volatile("v_fma_mixhi_f16 %0, -%1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(e.l[pr]) : "v"(e.h[pr]), "s"(one), "v"(e.v[2 * pr + 1]));
+            } else if (q == 39) {
+                lds_stq(sl, make_uint4(e.h[0], e.h[1], e.h[2], e.h[3]));
+            } else if (q == 40) {
+                lds_stq(sl + 128, make_uint4(e.l[0], e.l[1], e.l[2], e.l[3]));
+            } else if (q == 41) {
+                if constexpr (DUMP) {
+                    st4(dlane + t * dstep, make_float4(e.v[0], e.v[1], e.v[2], e.v[3]));
+                    st4(dlane + t * dstep + 4, make_float4(e.v[4], e.v[5], e.v[6], e.v[7]));
+                }
             }
         };
         const int cthis = (j - 1) * BODY_CHUNKS_K7;
         const int cnext = (j * BODY_CHUNKS_K7) % NCHUNK_STEP;          // the layer after the step's last one is the next step's first
-        Epi ep[2];
+        constexpr int NU = 2 * NN * HC;                                // units per layer
+        Epi ep;                                   // one is enough: a tile's queue is over before the next tile's starts
         uint4 bq[NB][2];
+        // prologue: address of unit 0, fragments of units 0 .. PD-1 (same tap), address of unit PD
+        static_assert(PD == 2, "the prologue and the gap table are written for a prefetch distance of two units");
 #pragma unroll
-        for (int g = 0; g < PD; ++g) bload(bq[g % NB], g / HC, g % HC);
+        for (int k = 0; k < 3; ++k) addr_op(0, k);
+        frag_read(bq[0][0], 0, 0); frag_read(bq[0][1], 0, 1);
+        frag_read(bq[1][0], 1, 0); frag_read(bq[1][1], 1, 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) addr_op(PD, k);
         STAMP_ADD(3);                             // layer set-up
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
+#ifdef STOF_STAMP_PASSA
+            if (ps == 1) STAMP_ADD(3);            // diagnostic: pass A is then counted with the layer set-up (slot 3)
+#endif
 #pragma unroll
             for (int n = 0; n < NN; ++n) {
 #pragma unroll
                 for (int c = 0; c < HC; ++c) {
-                    const int g = (ps * NN + n) * HC + c;              // position in the layer's sequence of 84 (tile, chunk) units
-                    if (g + PD < 2 * NN * HC) {
-                        const int g2 = g + PD;
-                        bload(bq[g2 % NB], (g2 / HC) % NN, (g2 / (NN * HC)) * HC + g2 % HC);
-                    }
-                    if (BWD && KIND == 3 && ps == 1 && c == 0) ys_load(n);
+                    const int g = (ps * NN + n) * HC + c;              // position in the layer's sequence of 84 units
                     const uint4 (&b)[2] = bq[g % NB];
                     const uint4 (&w)[FRAGS_PER_CHUNK] = W[ps][c];
                     floatx4 (&a)[2] = acc[n];
                     const bool first = ps == 0 && c == 0;            // the layer's bias enters as the C operand of the first MFMA
-                    a[0] = mfma16(w[0], b[0], first ? bvec[0] : a[0]);
-                    a[1] = mfma16(w[2], b[0], first ? bvec[1] : a[1]);
-                    a[0] = mfma16(w[0], b[1], a[0]);
-                    a[1] = mfma16(w[2], b[1], a[1]);
-                    a[0] = mfma16(w[1], b[0], a[0]);
-                    a[1] = mfma16(w[3], b[0], a[1]);
-                    // the other half's weights, one chunk per tile (the last tile: two), a whole pass ahead of their use
-                    if (c == 3 || (n == NN - 1 && c == 1)) {
-                        const int cw = (c == 3) ? n : HC - 1;
-                        const int csrc = ps == 0 ? cthis + HC + cw : cnext + cw;
-#pragma unroll
-                        for (int f = 0; f < FRAGS_PER_CHUNK; ++f) W[ps ^ 1][cw][f] = wload(csrc, f);
-                    }
-                    if (ps == 1 && n > 0) piece(ep[(n - 1) & 1], n - 1, c);
+                    const bool epi = ps == 1 && n > 0;               // the previous tile's epilogue rides behind this unit
+                    Epi& e = ep;
 #pragma unroll
                     for (int i = 0; i < 6; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        // hi*hi, hi*lo, lo*hi of M-tiles 0 and 1, alternating accumulators
+                        a[i & 1] = mfma16(w[2 * (i & 1) + (i >= 4 ? 1 : 0)], b[(i >> 1) == 1 ? 1 : 0], (first && i < 2) ? bvec[i & 1] : a[i & 1]);
+                        // E slots of the unit: gaps 0, 1 (one each, beside the fragment reads), 2 (two), 3, 4 (one each)
+                        const int ga = g + PD + 1;                     // its fragments are requested in the next unit
+                        const bool na = ga < NU && new_tap(ga);
+                        if (i < 2) {
+                            if (g + PD < NU) frag_read(bq[(g + PD) % NB][i], g + PD, i);
+                            if (epi) epi_op(e, n - 1, 6 * c + i);
+                            // the slot of pass-B tile t is its (tile, tap 3) operand address, live in `aq` while unit NN HC + HC t - PD runs
+                            if (i == 0 && g >= NN * HC - PD && (g + PD) % HC == 0) { slotq[unit_tile(g + PD) % 3] = aq + slotdelta; STOF_PIN(slotq[unit_tile(g + PD) % 3]); }
+                        } else if (i == 2) {
+                            if (epi) { epi_op(e, n - 1, 6 * c + 2); epi_op(e, n - 1, 6 * c + 3); }
+                        } else if (i < 5) {
+                            if (epi) epi_op(e, n - 1, 6 * c + i + 1);
+                            if (na) addr_op(ga, i - 3);                // one address instruction per gap: the three form a dependent chain
+                        } else {
+                            if (na) addr_op(ga, 2);
+                            // the other half's weights a whole pass ahead of their use: one fragment per unit
+                            const int li = n * (HC - 1) + c;
+                            if (c < HC - 1 && li < HC * FRAGS_PER_CHUNK) {
+                                const int cw = li / FRAGS_PER_CHUNK, f = li % FRAGS_PER_CHUNK;
+                                W[ps ^ 1][cw][f] = wload((ps == 0 ? cthis + HC : cnext) + cw, f);
+                            }
+                            if (BWD && KIND == 3 && ps == 1 && c == HC - 1) ys_load(n);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-                    __builtin_amdgcn_sched_barrier(0);     // one scheduling region per unit: prefetches stay where they are written
                 }
             }
         }
         STAMP_ADD(4);                             // both passes incl. the overlapped epilogues
 #pragma unroll
-        for (int k = 0; k < HC; ++k) piece(ep[(NN - 1) & 1], NN - 1, k);
+        for (int q = 0; q < 42; ++q) epi_op(ep, NN - 1, q);
         // Rows outside [0, L) of their waveform (gap rows, stream ends, segment padding) must read as zeros for the next layer
-        // (= its zero padding): the lanes of padding rows overwrite what the branch-free pieces stored (same lane, program
+        // (= its zero padding): the lanes of padding rows overwrite what the branch-free epilogue stored (same lane, program
         // order: no race; the barrier follows), and the training dump takes the valid rows of the span from the LDS image.
         if (!span_ok) {
 #pragma unroll 1
@@ -435,6 +511,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
         STAMP_ADD(5);                             // exposed epilogue (last tile) + padding fix-up
         __syncthreads();
         STAMP_ADD(2);
+#undef STOF_PIN
     };
 
     // conv_last with r <= 16: one 16-channel output tile on v_mfma_f32_16x16x32_f16, every wave 48 rows of the step (as r3)
@@ -634,12 +711,22 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                 __syncthreads();
                 STAMP_ADD(2);
             }
-            layer(std::integral_constant<int, 0>{}, 11);
+            {
+                // the layer number as a value the optimiser cannot see through: with a literal 11 it hoists the lane addresses of
+                // the layer's 56 weight fragments out of the step loop (112 registers), spills them and reloads each behind vmcnt(0)
+                int j12;
+                asm volatile("s_mov_b32 %0, 11" : "=s"(j12));
+                layer(std::integral_constant<int, 0>{}, j12);
+            }
             if (p.last16 != nullptr) conv_last16();
             else conv_last_wide();
         } else {
             // conv12^T plain, then (conv(2k+3)^T times lrelu'(saved), conv(2k+2)^T added in place) x 5
-            layer(std::integral_constant<int, 2>{}, 1);
+            {
+                int j1;                             // opaque for the same reason as conv12's layer number in the forward sweep
+                asm volatile("s_mov_b32 %0, 1" : "=s"(j1));
+                layer(std::integral_constant<int, 2>{}, j1);
+            }
 #pragma unroll 1
             for (int pp = 0; pp < 5; ++pp) {
                 layer(std::integral_constant<int, 3>{}, 2 * pp + 2);
