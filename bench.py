@@ -61,6 +61,10 @@ def parse_args(argv=None):
                     help="C5: 'fused' = StofNetTrainer (loss + AdamW kernels); 'autograd' = the reference's torch loss / "
                          "torch.optim.AdamW lines on the module's autograd boundary (main.py:221-248)")
     ap.add_argument('--rows', type=int, default=0, help='override the rows per GPU of the chosen config (smoke runs)')
+    ap.add_argument('--cpu-sample-rows', type=int, default=0,
+                    help='rows of the bounded CPU-oracle sample (default: 256; C4 128; the extra configs of the default run use 32)')
+    ap.add_argument('--no-extra-configs', action='store_true',
+                    help='default run (C2, one GPU): do not measure C3 / C4 / C5 afterwards (extras.configs)')
     ap.add_argument('--dry-run', action='store_true',
                     help='rehearse the launcher and the distributed plumbing on the CPU (gloo, no kernels): tests only')
     ap.add_argument('--rehearse-on-one-gpu', action='store_true',
@@ -109,7 +113,7 @@ def _stop(procs, grace=5.0):
 def launch_children(args, argv):
     """One child per GPU; all of them are polled.  The first non-zero exit (or the watchdog) ends the siblings at once
     and the launcher returns non-zero with the failing rank's stderr tail: a dead rank cannot leave rank 0 waiting in
-    RCCL init / a barrier until the process-group timeout.  Per-rank stderr goes to <logdir>/bench_rank<r>.err."""
+    RCCL init / a barrier until the process-group timeout.  Per-rank stderr goes to <logdir>/bench_rank<r>.<launcher pid>.err."""
     port = os.environ.get('MASTER_PORT') or str(free_port())
     logdir = os.environ.get('STOF_BENCH_LOGDIR') or os.path.join(ROOT, 'gpurun_out')
     os.makedirs(logdir, exist_ok=True)
@@ -120,7 +124,7 @@ def launch_children(args, argv):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        err_path = os.path.join(logdir, f'bench_rank{rank}.err')
+        err_path = os.path.join(logdir, f'bench_rank{rank}.{os.getpid()}.err')
         ferr = open(err_path, 'wb')
         fout = open(out0_path, 'wb') if rank == 0 else subprocess.DEVNULL
         files += [ferr] + ([fout] if rank == 0 else [])
@@ -215,6 +219,11 @@ def cpu_baseline(sd, r, L, x_np, y_gpu=None, idx_gpu=None, threshold=None, reps=
         for _ in range(reps):
             y_ref = so.stofnet_forward(sd, x_np, r)
         dt = (time.perf_counter() - t0) / reps
+        b64 = None
+        if rows >= 64:                                # SURVEY 8d names N = 1 and N = 64
+            t0 = time.perf_counter()
+            so.stofnet_forward(sd, x_np[:64], r)
+            b64 = time.perf_counter() - t0
         so.stofnet_forward(sd, x_np[:1], r)
         t0, p0 = time.perf_counter(), time.process_time()
         for _ in range(5):
@@ -226,6 +235,8 @@ def cpu_baseline(sd, r, L, x_np, y_gpu=None, idx_gpu=None, threshold=None, reps=
            'batch1': {'waveforms_per_s': round(1.0 / w1, 2), 'wall_ms': round(w1 * 1e3, 2),
                       'process_time_ms': round(p1 * 1e3, 2),
                       'note': 'C1 shape [1,1,L]; process_time = CPU time over all threads, the reference\'s main.py:313-315 method'}}
+    if b64 is not None:
+        out['batch64'] = {'waveforms_per_s': round(64.0 / b64, 2), 'wall_ms': round(b64 * 1e3, 1)}
     if y_gpu is not None:
         y_ref = y_ref.numpy()
         prow = min(rows, 64 if threshold else rows)
@@ -434,6 +445,7 @@ def train_bench(args):
         step(s)
     dt = d.timed(step, args.steps)
     census = d.census()
+    d.finish()                                      # all collectives done: rank 0's CPU work below cannot time the group out
     if d.rank == 0:
         flops = 3.0 * total_flops(nb, L, R)        # forward + data-gradient + weight-gradient
         achieved = flops * args.steps / dt / 1e12
@@ -447,20 +459,24 @@ def train_bench(args):
         # `achieved` counts the ALGORITHMIC flops of the step (what the reference's dense autograd does).  Since r3 the two backward
         # passes of the SemiGlobalBlock's contract convolution (22.6 % of that count) work on the max-pool's sparse gradient and are
         # not multiplied out; `executed` leaves them out, i.e. it is the matrix-pipe work actually done per second.
-        sparse_sgb = os.environ.get('STOF_TRAIN_SGB_SPARSE', '1') != '0'
+        eng = tr if tr is not None else model._engine(d.dev, args.train_precision)
+        sparse_sgb = bool(getattr(eng, 'sgb_sparse_taken', False))      # what the engine's last backward really ran
         executed = (flops - (2.0 * 2.0 * nb * L * 163840 if sparse_sgb else 0.0)) * args.steps / dt / 1e12
+        # `achieved` / `frac` = the matrix-pipe work actually EXECUTED per second; the algorithmic count (what the reference's dense
+        # autograd multiplies out, 22.6 % more when the sparse SemiGlobalBlock backward is taken) is given beside it
         out['roofline'] = {'bound': 'mfma', 'kernel': f'whole step (sweeps + conv_wgrad / conv_cl16 kernels, {args.train_precision} MFMA)',
-                           'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                           'frac': round(achieved / peak, 4), 'traffic': None,
-                           'executed': round(executed, 2), 'executed_frac': round(executed / peak, 4)}
+                           'achieved': round(executed, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                           'frac': round(executed / peak, 4), 'traffic': None,
+                           'algorithmic': round(achieved, 2), 'algorithmic_frac': round(achieved / peak, 4),
+                           'sparse_sgb_backward_taken': sparse_sgb}
         out['final_loss'] = float(last['loss'])
         out['ranks'] = census
-        if not args.no_cpu_baseline:       # rank 0 only; at N > 1 the other ranks wait in finish()'s barrier meanwhile
+        if not args.no_cpu_baseline:       # rank 0 only (the process group is already closed)
             # the oracle's training step (torch autograd on the host cores), bounded sample
             from oracle import train_oracle
             cores = host_cores()
             torch.set_num_threads(cores)
-            rows = min(32, nb)
+            rows = min(args.cpu_sample_rows or 32, nb)
             xs, gts = x[:rows].cpu().numpy(), gt[:rows].cpu().numpy()
             train_oracle.loss_and_grads(sd, xs[:4], gts[:4], R, 80, dtype=torch.float32)
             t1 = time.perf_counter()
@@ -468,8 +484,58 @@ def train_bench(args):
             cdt = time.perf_counter() - t1
             out['cpu_baseline'] = {'value': round(rows / cdt, 2), 'unit': 'waveforms/s', 'cores': cores, 'kind': 'port',
                                    'sample': f'1 fwd+bwd of {rows} waveforms (oracle, torch autograd fp32), optimizer step excluded'}
+            if tr is not None:
+                # the checker: loss and every parameter gradient of the engine, at its CURRENT weights, against the oracle's
+                # autograd (float64) on the first rows of the batch
+                prow = min(8, nb)
+                cur = {k: v.detach().cpu().numpy().copy() for k, v in tr.p.items()}
+                gl, _ = tr.forward_backward(x[:prow], gt[:prow])
+                g_gpu = {k: v.detach().cpu().numpy().copy() for k, v in tr.g.items()}
+                ol, og, _ = train_oracle.loss_and_grads(cur, x[:prow].cpu().numpy(), gt[:prow].cpu().numpy(), R, 80, dtype=torch.float64)
+                worst = max(float(np.abs(g_gpu[k] - og[k]).max() / max(np.abs(og[k]).max(), 1e-30)) for k in og)
+                out['parity_on_sample'] = {'rows': prow, 'loss_rel_err': abs(float(gl) - ol) / abs(ol),
+                                           'max_grad_err_rel_to_max_abs_grad': worst,
+                                           'note': 'engine (weights after the timed steps) vs oracle autograd in float64'}
         print(json.dumps(out), flush=True)
-    d.finish()
+
+
+def run_extra_configs(args):
+    """The other BASELINE configs under the same clock as the default (C2) line: each is this script again as a CHILD process
+    (started with subprocess after the C2 timed region -- never an exec of this GPU process), a short run with a small CPU
+    sample; its line is distilled to {value, ms_per_step, roofline, parity_on_sample, ...}."""
+    runs = [('C3', ['--config', 'C3', '--steps', '5', '--warmup', '1']),
+            ('C4', ['--config', 'C4', '--steps', '2', '--warmup', '1']),
+            ('C5', ['--config', 'C5', '--steps', '20', '--warmup', '3']),
+            ('C5_batch4', ['--config', 'C5', '--steps', '20', '--warmup', '3', '--rows', '4'])]
+    out = {}
+    for name, extra in runs:
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-extra-configs', '--no-fp32-extra',
+               '--cpu-sample-rows', '32', '--precision', args.precision, '--train-precision', args.train_precision] + extra
+        t0 = time.perf_counter()
+        try:
+            pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=float(os.environ.get('STOF_EXTRA_TIMEOUT', '150')))
+            line = [ln for ln in pr.stdout.decode(errors='replace').splitlines() if ln.startswith('{')]
+            if pr.returncode != 0 or not line:
+                out[name] = {'error': f'exit code {pr.returncode}', 'stderr_tail': pr.stderr.decode(errors='replace')[-400:]}
+                continue
+            rec = json.loads(line[-1])
+        except subprocess.TimeoutExpired:
+            out[name] = {'error': 'timed out'}
+            continue
+        keep = {k: rec[k] for k in ('metric', 'value', 'unit', 'steps', 'ms_per_step', 'dtype', 'roofline', 'kernels_ms', 'final_loss',
+                                    'parity_on_sample') if k in rec}
+        keep['workload'] = rec['config']['workload']
+        if 'cpu_baseline' in rec:
+            keep['cpu_baseline'] = {k: rec['cpu_baseline'][k] for k in ('value', 'unit', 'cores', 'sample') if k in rec['cpu_baseline']}
+            if 'parity_on_sample' in rec['cpu_baseline']:
+                keep['parity_on_sample'] = rec['cpu_baseline']['parity_on_sample']
+        ex = rec.get('extras', {})
+        for k in ('forward_only_ms_per_step', 'picker_threshold_ms_per_step', 'detections_per_row_mean', 'kmax', 'fused_argmax_onsets'):
+            if k in ex:
+                keep[k] = ex[k]
+        keep['child_wall_s'] = round(time.perf_counter() - t0, 1)
+        out[name] = keep
+    return out
 
 
 def load_fixture_weights(key):
@@ -622,12 +688,19 @@ def infer_bench(args):
         torch.cuda.synchronize()
         fdt_ns = (time.perf_counter() - t1) / 5
         kmax_ns = int(res['fused'][0].max())
+        stream_overflow = bool(model.onsets_overflowed())            # sticky range-guard word of ALL sync=False calls above
+        stream_truncated = bool((res['fused'][0] > res['fused'][1].shape[1]).any())
+        if stream_overflow or stream_truncated:
+            raise SystemExit(f'bench.py: fused onsets stream invalid (fp16 range overflow: {stream_overflow}, '
+                             f'row list truncated: {stream_truncated})')
         fc, fi = model.forward_onsets(x[:chunk], 20)
         rc, ri = onset_indices(model(x[:chunk]), 20, None)
         extras['fused_argmax_onsets'] = {'ms_per_step': round(fdt_ns * 1e3, 3), 'waveforms_per_s': round(d.world * rows / fdt_ns, 1),
                                          'ms_per_step_with_host_sync': round(fdt * 1e3, 3),
                                          'waveforms_per_s_with_host_sync': round(d.world * rows / fdt, 1),
                                          'kmax_read_after_loop': kmax_ns,
+                                         'range_guard_sticky_word_after_loop': int(stream_overflow),
+                                         'rows_truncated_after_loop': int(stream_truncated),
                                          'identical_to_map_plus_picker': bool(torch.equal(fc, rc) and torch.equal(fi, ri)),
                                          'note': 'StofNet.forward_onsets(sync=False): output = onset indices only, counts and the '
                                                  'range-guard word read once after the timed loop; the *_with_host_sync figures '
@@ -663,6 +736,9 @@ def infer_bench(args):
         del m32, y32
     extras['auto_mode_fp32_rerun_taken'] = bool(fell_back)
     census = d.census()
+    # every collective is over: the ranks part here, so that rank 0's CPU baseline (tens of seconds on the host cores) cannot
+    # run into the process group's timeout while the others wait in a barrier
+    d.finish()
 
     if d.rank == 0:
         launch_rows = min(chunk, 4096)              # stof_forward sweeps sub-batches of <= 4096 rows per launch
@@ -699,13 +775,18 @@ def infer_bench(args):
         out['whole_forward_tflops'] = round(total_flops(rows, L, R) * d.world * args.steps / dt / 1e12, 2)
         out['extras'] = extras
         out['ranks'] = census
-        if not args.no_cpu_baseline:       # rank 0 only; at N > 1 the other ranks wait in finish()'s barrier meanwhile
-            srows = 256 if cfg != 'C4' else 128
+        if not args.no_cpu_baseline:       # rank 0 only (the process group is already closed)
+            srows = args.cpu_sample_rows or (256 if cfg != 'C4' else 128)
+            srows = min(srows, rows)
             xs = x[:srows].cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(sd, R, L, xs, y[:srows] if cfg != 'C4' else model(x[:srows]),
                                                idx[:srows], threshold=th)
+        if cfg == 'C2' and d.world == 1 and not args.no_extra_configs and not args.rows:
+            # BASELINE.json configs[2..4] under the same clock, after the headline's timed region (headline keys unchanged)
+            del y
+            torch.cuda.empty_cache()
+            extras['configs'] = run_extra_configs(args)
         print(json.dumps(out), flush=True)
-    d.finish()
 
 
 def main(argv=None):

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
     float* const rawr = smem + Lds::RAW;
     float* const biasl = smem + Lds::BIAS;
     float* const sgl = smem + Lds::SGL;
+    float* const c1l = smem + Lds::TOTAL;         // [64][10] conv1 taps + bias (BODY_P2_C1F floats behind the r3 layout)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,14 +72,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
     // ---- one-time setup: zero rings, biases to LDS, conv1 taps to registers
     for (int i = tid; i < Lds::RAW + RAWRING; i += 256) smem[i] = 0.f;
     for (int i = tid; i < 13 * 64; i += 256) biasl[i] = p.bias[i];
+    for (int i = tid; i < BODY_P2_C1F; i += 256) c1l[i] = p.c1[i];
     const int cq = tid & 15, rl = tid >> 4;
-    float w1[4][9], b1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int d = 0; d < 9; ++d) w1[i][d] = p.c1[(4 * cq + i) * 10 + d];
-        b1[i] = p.c1[(4 * cq + i) * 10 + 9];
-    }
     __syncthreads();
     auto decode_row = [&](int nB, int tB, int off, int& n, int& t) {
         n = nB;
@@ -94,6 +89,23 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
     const float one_x0 = opaque_one();
     auto x0_pass = [&](char* dst, int rstart, int nR, int tR, bool dump_it) {
         constexpr int NIT = S / 16;
+        // the thread's 4 channels x (9 taps + bias) from LDS, ten 16-byte reads: kept in registers they cost 40 of them for the
+        // whole step, and the hand-placed layers need the room (a spill inside a layer costs more than a step's worth of reloads)
+        float w1[4][9], b1[4];
+        {
+            float wv[40];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const float4 t4 = ld4(c1l + 40 * cq + 4 * i);
+                wv[4 * i] = t4.x; wv[4 * i + 1] = t4.y; wv[4 * i + 2] = t4.z; wv[4 * i + 3] = t4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int d = 0; d < 9; ++d) w1[i][d] = wv[10 * i + d];
+                b1[i] = wv[10 * i + 9];
+            }
+        }
         float* const dump0 = (DUMP && dump_it) ? p.dump : nullptr;
         const int g0 = rstart + rl * NIT;
         if (!seg_mode && rstart >= 0 && rstart + S <= gend && tR + S <= L &&
@@ -254,7 +266,10 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
 #endif
     constexpr int NN = S / 32;                    // N-tiles (16 rows) per wave
     static_assert(NN == 6, "the two-pass layer is written for six N-tiles per wave (S = 192)");
-    constexpr int PD = 2, NB = PD + 1;            // activation fragments are requested PD chunks ahead of their MFMAs
+#ifndef STOF_P2_PD
+#define STOF_P2_PD 2
+#endif
+    constexpr int PD = STOF_P2_PD, NB = PD + 1;   // activation fragments are requested PD units ahead of their MFMAs
     const int i16 = lane & 15, q4 = lane >> 4;
     auto mfma16 = [](const uint4& a, const uint4& b, floatx4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(a), as_h8(b), c, 0, 0, 0);
@@ -427,13 +442,14 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
         Epi ep;                                   // one is enough: a tile's queue is over before the next tile's starts
         uint4 bq[NB][2];
         // prologue: address of unit 0, fragments of units 0 .. PD-1 (same tap), address of unit PD
-        static_assert(PD == 2, "the prologue and the gap table are written for a prefetch distance of two units");
+        static_assert(PD == 2 || PD == 3, "the prologue is written for a prefetch distance of two or three units");
 #pragma unroll
         for (int k = 0; k < 3; ++k) addr_op(0, k);
         frag_read(bq[0][0], 0, 0); frag_read(bq[0][1], 0, 1);
         frag_read(bq[1][0], 1, 0); frag_read(bq[1][1], 1, 1);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) addr_op(PD, k);
+        for (int k = 0; k < 3; ++k) addr_op(2, k);
+        if constexpr (PD == 3) { frag_read(bq[2][0], 2, 0); frag_read(bq[2][1], 2, 1); }   // unit 3 shares unit 2's tap
         STAMP_ADD(3);                             // layer set-up
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
@@ -467,12 +483,23 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                             if (epi) { epi_op(e, n - 1, 6 * c + 2); epi_op(e, n - 1, 6 * c + 3); }
                         } else if (i < 5) {
                             if (epi) epi_op(e, n - 1, 6 * c + i + 1);
+                            // the last tile's own old-value reads (its queue runs exposed after the loop): the previous tile's
+                            // queue is past its last use of them, and these two gaps of the layer's last unit carry no address
+                            if (ps == 1 && n == NN - 1 && c == HC - 1) epi_op(e, n, i - 3);
+#ifndef STOF_P2_DIAG_NOA
                             if (na) addr_op(ga, i - 3);                // one address instruction per gap: the three form a dependent chain
+#endif
                         } else {
+#ifndef STOF_P2_DIAG_NOA
                             if (na) addr_op(ga, 2);
-                            // the other half's weights a whole pass ahead of their use: one fragment per unit
+#endif
+                            // the other half's weights a whole pass ahead of their use: one fragment per unit (28 of a pass's 42)
                             const int li = n * (HC - 1) + c;
+#ifdef STOF_P2_DIAG_NOG
+                            if (false) {
+#else
                             if (c < HC - 1 && li < HC * FRAGS_PER_CHUNK) {
+#endif
                                 const int cw = li / FRAGS_PER_CHUNK, f = li % FRAGS_PER_CHUNK;
                                 W[ps ^ 1][cw][f] = wload((ps == 0 ? cthis + HC : cnext) + cw, f);
                             }
@@ -484,8 +511,9 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
             }
         }
         STAMP_ADD(4);                             // both passes incl. the overlapped epilogues
+        // the last tile's epilogue has nothing to hide behind
 #pragma unroll
-        for (int q = 0; q < 42; ++q) epi_op(ep, NN - 1, q);
+        for (int q = 2; q < 42; ++q) epi_op(ep, NN - 1, q);
         // Rows outside [0, L) of their waveform (gap rows, stream ends, segment padding) must read as zeros for the next layer
         // (= its zero padding): the lanes of padding rows overwrite what the branch-free epilogue stored (same lane, program
         // order: no race; the barrier follows), and the training dump takes the valid rows of the span from the LDS image.

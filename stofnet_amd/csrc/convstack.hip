@@ -1297,6 +1297,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_kernel(const BodyParams p) 
 #endif
 }
 
+constexpr int BODY_P2_C1F = 640;        // conv1 taps + bias [64][10] kept in LDS by the two-pass sweep (re-read per x0 pass: frees 40 registers)
 #include "body_p2.h"      // round 4: the split-fp16 sweep with two-pass tile-major k7 layers (the default)
 
 // ----------------------------------------------------------------------------------
@@ -1676,11 +1677,12 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
     constexpr int SHAPE_FAST = PREC == STOF_PREC_F16X3 ? 16 : 32;
     using Lds = BodyLds<BODY_S, BODY_RING, BODY_RAWRING>;
     using Lds16 = BodyLds<BODY_S, BODY_RING, BODY_RAWRING, ROWF16>;
-    const size_t body_lds_bytes = body16 ? Lds16::BYTES : Lds::BYTES;
+    const size_t body_p2_bytes = Lds16::BYTES + BODY_P2_C1F * sizeof(float);
+    const size_t body_lds_bytes = body_p2 ? body_p2_bytes : body16 ? Lds16::BYTES : Lds::BYTES;
     static LdsLimitOnce body_lds, body16_lds, body_p2_lds, sgb_lds;     // one per template instantiation (PREC)
     if (body_p2) {
         if (int st = body_p2_lds.ensure(reinterpret_cast<const void*>(&body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING>),
-                                        (int)Lds16::BYTES)) return st;
+                                        (int)body_p2_bytes)) return st;
     } else if (body16) {
         if (int st = body16_lds.ensure(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING, SHAPE_FAST>),
                                        (int)Lds16::BYTES)) return st;
@@ -2038,8 +2040,9 @@ extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev,
     static const bool p2 = body_p2_enabled();
     auto kernel = p2 ? &body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING, true, false>
                      : &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, false>;
+    const size_t lds_bytes = Lds16::BYTES + (p2 ? BODY_P2_C1F * sizeof(float) : 0);
     static LdsLimitOnce lds;
-    if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)Lds16::BYTES)) return st;
+    if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)lds_bytes)) return st;
     const float* base = static_cast<const float*>(blob_dev);
     BodyParams bp;
     bp.x = x; bp.sgb = has_sgb ? sgb_expand : nullptr; bp.y = y;
@@ -2052,7 +2055,7 @@ extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev,
     bp.gin = nullptr; bp.fwd_dump = nullptr;
     int64_t wgs = 0;
     if (int st = train_sweep_geometry(desc, bp, N, L, &wgs)) return st;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), Lds16::BYTES, stream, bp);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), lds_bytes, stream, bp);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
@@ -2165,8 +2168,9 @@ extern "C" int stof_train_sweep_bwd(const stof_net_desc* desc, const void* blob_
     static const bool p2 = body_p2_enabled();
     auto kernel = p2 ? &body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING, true, true>
                      : &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, true>;
+    const size_t lds_bytes = Lds16::BYTES + (p2 ? BODY_P2_C1F * sizeof(float) : 0);
     static LdsLimitOnce lds;
-    if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)Lds16::BYTES)) return st;
+    if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)lds_bytes)) return st;
     const float* base = static_cast<const float*>(blob_dev);
     BodyParams bp;
     bp.x = nullptr; bp.sgb = nullptr; bp.y = nullptr;
@@ -2178,7 +2182,7 @@ extern "C" int stof_train_sweep_bwd(const stof_net_desc* desc, const void* blob_
     bp.gin = g6; bp.fwd_dump = fwd_dump;
     int64_t wgs = 0;
     if (int st = train_sweep_geometry(desc, bp, N, L, &wgs)) return st;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), Lds16::BYTES, stream, bp);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), lds_bytes, stream, bp);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

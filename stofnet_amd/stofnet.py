@@ -112,6 +112,7 @@ class StofNet(nn.Module):
         self._packed = {}
         self._workspace = None
         self._status = None
+        self._sticky_status = None        # range-guard word of forward_onsets(sync=False): ORed by the kernels, cleared by the caller
 
     # ---- kernel-side state -------------------------------------------------
     def _supported(self):
@@ -258,8 +259,11 @@ class StofNet(nn.Module):
         that overflows the fp16 range in 'auto' mode) this falls back to forward() + the picker kernel.
 
         sync=False (serving loops, bench.py): no host read at all -- returns (counts[N], idx[N, cap]) as launched; entries
-        beyond a row's count are undefined, a count above `cap` means the row's list is truncated, and the caller checks
-        `fell_back_to_fp32()` / counts once per many calls instead of once per call."""
+        beyond a row's count are undefined and a count above `cap` means the row's list is truncated (the caller's check:
+        `(counts > cap).any()`).  The fp16-range guard of these calls is STICKY: the kernels OR into one word that is never
+        cleared by a call, so `onsets_overflowed()` -- one host read, whenever the caller likes -- tells whether ANY call
+        since the last check left the fp16 range (their onsets are then not to be trusted: re-run those inputs with
+        sync=True or precision='fp32'); no exact-fp32 re-run happens in this mode."""
         from .mask2samples import onset_indices
         _lib.require_device(x, 'x')
         if x.dim() != 3 or x.shape[1] != self.in_channels:
@@ -283,16 +287,21 @@ class StofNet(nn.Module):
             self._workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
         if self._status is None or self._status.device != x.device:
             self._status = torch.zeros(1, dtype=torch.int32, device=x.device)
+        if not sync and (self._sticky_status is None or self._sticky_status.device != x.device):
+            self._sticky_status = torch.zeros(1, dtype=torch.int32, device=x.device)
         y = torch.empty((n, 1, L * r), dtype=torch.float32, device=x.device) if return_map else None
         while True:
             counts = torch.empty((n,), dtype=torch.int32, device=x.device)
             idx = torch.empty((n, cap), dtype=torch.int32, device=x.device)
-            self._status.zero_()
+            if sync:
+                self._status.zero_()
+            # sync=False: the sticky word, never zeroed here (the kernel ORs into it); see onsets_overflowed()
+            status = self._status if sync else self._sticky_status
             with torch.cuda.device(x.device):
                 code = lib.stof_forward_onsets(ctypes.byref(desc), _lib.ptr(packed), _lib.ptr(xc), _lib.ptr(y), n, L,
                                                int(window_size), _lib.ptr(counts), _lib.ptr(idx), cap,
                                                _lib.ptr(self._workspace), self._workspace.numel(),
-                                               _lib.stream_ptr(x.device), _lib.ptr(self._status))
+                                               _lib.stream_ptr(x.device), _lib.ptr(status))
             if code == _lib.STOF_ERR_UNSUPPORTED:
                 return via_map()
             if code == _lib.STOF_ERR_ODD_SGB_REMAINDER or code == _lib.STOF_ERR_POOL_EMPTY:
@@ -314,6 +323,16 @@ class StofNet(nn.Module):
             cap = kmax                                            # a row with more ties than the buffer holds: once more
         idx = idx[:, :kmax]
         return (counts, idx, y) if return_map else (counts, idx)
+
+    def onsets_overflowed(self, clear=True) -> bool:
+        """forward_onsets(sync=False): synchronise and tell whether ANY such call since the last check produced a non-finite
+        value (an activation left the fp16 range); clears the sticky word unless clear=False."""
+        if self._sticky_status is None:
+            return False
+        hit = int(self._sticky_status.item()) != 0
+        if hit and clear:
+            self._sticky_status.zero_()
+        return hit
 
     def fell_back_to_fp32(self) -> bool:
         """'auto' mode: synchronise and tell whether the LAST forward took the exact-fp32 re-run."""

@@ -297,6 +297,7 @@ class TrainEngine:
                                                               _lib.ptr(g_x0), _lib.ptr(g_a1), n, L, P, cm, S, _lib.ptr(ws), ws.numel(), st)
                     if dcode != U:
                         _lib.check(dcode, 'stof_train_sgb_contract_dgrad')
+            self.sgb_sparse_taken = (wcode != U and dcode != U)        # bench.py: which route this backward really ran
             if wcode == U or dcode == U:
                 gc = torch.empty((n, L, cm), dtype=torch.float32, device=self.dev)
                 _lib.check(lib.stof_train_pool_bwd(_lib.ptr(gpool), _lib.ptr(arg), _lib.ptr(c), _lib.ptr(pooled), _lib.ptr(gc), n, L, P, cm, S, st),

@@ -32,6 +32,15 @@ FILL = {
     'mixlo2': ['v_fma_mixlo_f16 %[f0], %[f1], %[f2], %[f3] op_sel_hi:[1,0,0]', 'v_fma_mixhi_f16 %[f0], %[f1], %[f2], %[f3] op_sel_hi:[1,0,0]'],
     'dsw128_sixth': None,        # one ds_write_b128 behind every sixth MFMA
     'dsw64_third': None,         # one ds_write_b64 behind every third MFMA
+    'wait1': ['s_waitcnt lgkmcnt(15)'],
+    'wait2': ['s_waitcnt lgkmcnt(15)', 's_waitcnt vmcnt(63)'],
+    'wait1_add2': ['s_waitcnt lgkmcnt(15)', 'v_add_f32 %[f0], %[f0], %[f0]', 'v_add_f32 %[f1], %[f1], %[f1]'],
+    'nop1_add2': ['s_nop 0', 'v_add_f32 %[f0], %[f0], %[f0]', 'v_add_f32 %[f1], %[f1], %[f1]'],
+    'salu1_add2': ['s_add_u32 %[s0], %[s0], 1', 'v_add_f32 %[f0], %[f0], %[f0]', 'v_add_f32 %[f1], %[f1], %[f1]'],
+    'salu2_add2': ['s_add_u32 %[s0], %[s0], 1', 's_and_b32 %[s0], %[s0], 0xffff', 'v_add_f32 %[f0], %[f0], %[f0]', 'v_add_f32 %[f1], %[f1], %[f1]'],
+    'dsr_wait_add1': ['ds_read_b128 %[ld], %[addr]', 's_waitcnt lgkmcnt(15)', 'v_add_f32 %[f0], %[f0], %[f0]'],
+    'accrd_dep': ['v_accvgpr_read_b32 %[f0], %[spare]', 'v_add_f32 %[f1], %[f0], %[f1]'],
+    'add_dep2': ['v_add_f32 %[f0], %[f0], %[f1]', 'v_add_f32 %[f0], %[f0], %[f2]'],
 }
 NM = 48     # MFMAs per asm block
 def body(nacc, chain, fill):
@@ -72,15 +81,18 @@ out = ['// GENERATED by tools/micro/gen_issue_cost.py -- do not edit', '#include
        'typedef float floatx2 __attribute__((ext_vector_type(2)));']
 kernels = []
 only = sys.argv[2].split(',') if len(sys.argv) > 2 else None
-for cons in ['a', 'v']:
+for cons in ['a', 'v', 'A', 'W']:
     for nacc, chain in [(1, 1), (2, 1), (2, 3), (6, 1), (6, 3)]:
         for fill in FILL:
             if cons == 'v' and fill not in ('none', 'add1', 'add2', 'mix2', 'dsr128', 'accrd1'): continue
+            if cons in ('A', 'W') and fill not in ('none', 'add2', 'dsr128_third_add1', 'sweep_mix'): continue
             if (nacc, chain) not in [(2, 1), (2, 3)] and fill not in ('none', 'add1', 'add2', 'dsr128'): continue
-            if only and not (cons == 'a' and (nacc, chain) == (2, 1) and fill in only): continue
+            if only and not ((nacc, chain) == (2, 1) and fill in only and (cons == 'a' or cons in ('A', 'W', 'v'))): continue
             name = f'k_{cons}_{nacc}_{chain}_{fill}'
             kernels.append((name, cons, nacc, chain, fill))
-            accs = ', '.join(f'[c{i}] "+{cons}"(c{i})' for i in range(nacc))
+            acons = 'a' if cons in ('a', 'A') else 'v'          # accumulator file
+            wcons = 'a' if cons in ('A', 'W') else 'v'          # file of the A operands (weights)
+            accs = ', '.join(f'[c{i}] "+{acons}"(c{i})' for i in range(nacc))
             out.append(f'''__global__ __launch_bounds__(256, 1) void {name}(const uint4* __restrict__ w, float* out, int iters, unsigned long long* clk) {{
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -107,7 +119,7 @@ for cons in ['a', 'v']:
     for (int it = 0; it < iters; ++it) {{
         asm volatile("{body(nacc, chain, fill)}"
             : {accs}, [f0] "+v"(f0), [f1] "+v"(f1), [f2] "+v"(f2), [f3] "+v"(f3), [ld] "+v"(ld), [ld2] "+v"(ld2), [s0] "+s"(s0), [ga2] "+v"(ga2)
-            : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3),
+            : [a0] "{wcons}"(a0), [a1] "{wcons}"(a1), [a2] "{wcons}"(a2), [a3] "{wcons}"(a3), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3),
               [spare] "a"(spare), [addr] "v"(addr), [st] "v"(st), [gaddr] "v"(gaddr), [voff] "v"(voff), [voff64] "v"(voff64), [sbase] "s"(sbase), [rsrc] "s"(rsrc) : "memory");
     }}
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
