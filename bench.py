@@ -281,7 +281,9 @@ class Dist:
         if backend == 'nccl' and torch.cuda.device_count() < max(self.world, self.local_rank + 1):
             raise SystemExit(f'bench.py: rank {self.rank} sees {torch.cuda.device_count()} GPU(s) but WORLD_SIZE={self.world} '
                              f'(one process per GPU): refusing to start')
-        if self.world > 1:
+        # STOF_FORCE_PROCESS_GROUP=1: create the process group even for one rank, so a one-GPU box runs the RCCL path
+        # (communicator set-up, int32 all_gather, MAX / SUM all-reduces) that an 8-GPU node would (tests/test_rccl_one_rank.py)
+        if self.world > 1 or os.environ.get('STOF_FORCE_PROCESS_GROUP') == '1':
             import datetime
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -143,6 +143,10 @@ int stof_event_elapsed_ms(void* start, void* stop, float* ms_out);
  * in[N, C_in, W] -> out[N, C_in/r, W*r], out[n,c,w*r+k] = in[n,k*C+c,w].     */
 int stof_sample_shuffle(const float* in, float* out, int64_t N, int64_t C_in,
                         int64_t W, int32_t r, void* stream);
+/* The same permutation for elements of elem_bytes = 1, 2, 4, 8 or 16 bytes, bit for bit: the reference's
+ * view / permute / contiguous (utils/sample_shuffle.py:24-27) is dtype-agnostic (int64 ramps, float64, float16, complex). */
+int stof_sample_shuffle_bytes(const void* in, void* out, int64_t N, int64_t C_in,
+                              int64_t W, int32_t r, int32_t elem_bytes, void* stream);
 
 /* get_maxima_positions (utils/mask2samples.py:26-34) per row of scores[N,1,M]:
  * NMS window `window_size` (made odd, :7), then threshold mode (has_threshold
@@ -295,6 +299,10 @@ size_t stof_train_conv1_wgrad_workspace_bytes(void);
 int stof_train_conv1_wgrad(const float* x, const float* g, const float* saved, float* dw, float* db,
                            int64_t N, int64_t L, float out_scale, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* Gradient with respect to the input frame, which the reference's autograd yields for free (models/stofnet.py:45):
+ * dx[N][L] = out_scale * conv1^T(g * relu'(saved)), g and saved channel-last [N][L][64], w = conv1.weight (64,1,9).   */
+int stof_train_conv1_dgrad(const float* g, const float* saved, const float* w, float* dx, int64_t N, int64_t L,
+                           float out_scale, void* stream);
 /* SemiGlobalBlock pieces (models/stofnet.py:103,108-115), channel-last: MaxPool1d(scale, scale) with arg-max
  * (scale = sample_scale <= 256, P = floor(L / scale) windows), its routing backward (times lrelu' of the pre-pool
  * activation), nearest upsample x scale + pad (rem_half = (L - P*scale) / 2 on each side) + add and its backward.

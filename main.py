@@ -212,6 +212,8 @@ def train(model, frames, gt, cfg, log=None):
             tot += float(loss)
             if log is not None and log.enabled:
                 log.log({'train_step': e * len(mine) + (b - rank) // world + 1, 'train_loss': float(loss)})      # main.py:251-255
+        if not autograd:
+            tr.raise_if_overflow()           # split-fp16 training: the range guard's sticky word, once per epoch (fp32: never set)
         model.eval()
         val = 0.0
         with torch.no_grad():

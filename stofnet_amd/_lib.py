@@ -63,6 +63,8 @@ _SIGNATURES = {
     'stof_event_elapsed_ms': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_float)]),
     'stof_sample_shuffle': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32,
                                        _c.c_void_p]),
+    'stof_sample_shuffle_bytes': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32,
+                                             _c.c_int32, _c.c_void_p]),
     'stof_pick_maxima': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_float,
                                     _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
     'stof_indices_to_coords': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float,
@@ -104,6 +106,7 @@ _SIGNATURES = {
     'stof_train_conv1': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
     'stof_train_conv1_wgrad_workspace_bytes': (_c.c_size_t, []),
     'stof_train_conv1_wgrad': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    'stof_train_conv1_dgrad': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_void_p]),
     'stof_train_sweep_blob_bytes': (_c.c_size_t, [_c.c_void_p]),
     'stof_train_sweep_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'stof_train_sweep_dump_floats': (_c.c_size_t, [_c.c_int64, _c.c_int64]),

@@ -16,10 +16,13 @@ namespace {
 // w*r + k) are coalesced 4-byte-per-lane streams.
 // ----------------------------------------------------------------------------------
 constexpr int SHUF_TW = 256;      // w positions per tile
-__global__ __launch_bounds__(256) void sample_shuffle_kernel(const float* __restrict__ in,
-                                                             float* __restrict__ out, int C, int W, int r,
+// T = an unsigned integer type of the element's size (1, 2, 4, 8 or 16 bytes): the operation is a pure permutation of elements
+// (utils/sample_shuffle.py:24-27 is view / permute / contiguous on any dtype), so every dtype goes through bit for bit.
+template <typename T>
+__global__ __launch_bounds__(256) void sample_shuffle_kernel(const T* __restrict__ in, T* __restrict__ out, int C, int W, int r,
                                                              int tiles_w) {
-    extern __shared__ float tile[];                 // [r][TW + 1]
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+    T* const tile = reinterpret_cast<T*>(tile_raw);   // [r][TW + 1]
     const int tid = threadIdx.x;
     const int tw = blockIdx.x % tiles_w;
     const long long nc = blockIdx.x / tiles_w;      // n * C + c
@@ -27,12 +30,12 @@ __global__ __launch_bounds__(256) void sample_shuffle_kernel(const float* __rest
     const int c = (int)(nc - n * C);
     const int w0 = tw * SHUF_TW;
     const int wn = min(SHUF_TW, W - w0);
-    const float* src = in + (n * (long long)r * C + c) * W + w0;      // row k at + k*C*W
+    const T* src = in + (n * (long long)r * C + c) * W + w0;          // row k at + k*C*W
     const long long rs = (long long)C * W;
     // reads: four independent row loads in flight per thread before the first LDS store
     int k = 0;
     for (; k + 4 <= r; k += 4) {
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        T v0 = T(), v1 = T(), v2 = T(), v3 = T();
         if (tid < wn) { v0 = src[k * rs + tid]; v1 = src[(k + 1) * rs + tid]; v2 = src[(k + 2) * rs + tid]; v3 = src[(k + 3) * rs + tid]; }
         tile[k * (SHUF_TW + 1) + tid] = v0;
         tile[(k + 1) * (SHUF_TW + 1) + tid] = v1;
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256) void sample_shuffle_kernel(const float* __rest
     for (; k < r; ++k)
         if (tid < wn) tile[k * (SHUF_TW + 1) + tid] = src[k * rs + tid];
     __syncthreads();
-    float* dst = out + (nc * W + w0) * (long long)r;
+    T* dst = out + (nc * W + w0) * (long long)r;
     const int total = wn * r;
     const float inv_r = 1.0f / (float)r;
     for (int i = tid; i < total; i += 256) {
@@ -53,6 +56,7 @@ __global__ __launch_bounds__(256) void sample_shuffle_kernel(const float* __rest
         dst[i] = tile[kk * (SHUF_TW + 1) + w];
     }
 }
+struct alignas(16) shuf_u128 { unsigned long long lo, hi; };
 
 // ----------------------------------------------------------------------------------
 // pick_maxima: one work-group per row.  A sample is a detection iff
@@ -374,21 +378,40 @@ extern "C" int stof_reduce_echoes(const float* scores, int64_t N, int64_t M, con
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
-extern "C" int stof_sample_shuffle(const float* in, float* out, int64_t N, int64_t C_in, int64_t W, int32_t r,
-                                   void* stream) {
-    if (N < 0 || C_in < 0 || W < 0 || r < 1) return STOF_ERR_BAD_ARG;
-    if (C_in % r != 0) return STOF_ERR_CHANNELS;
-    if (N == 0 || C_in == 0 || W == 0) return STOF_OK;
-    if (!in || !out) return STOF_ERR_BAD_ARG;
-    if (r > 128) return STOF_ERR_UNSUPPORTED;
+namespace {
+template <typename T>
+int launch_shuffle(const void* in, void* out, int64_t N, int64_t C_in, int64_t W, int32_t r, void* stream) {
     const int64_t C = C_in / r;
     const int64_t tiles_w = (W + SHUF_TW - 1) / SHUF_TW;
     const int64_t blocks = N * C * tiles_w;
     if (blocks > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(sample_shuffle_kernel, dim3((unsigned)blocks), dim3(256),
-                       (size_t)r * (SHUF_TW + 1) * sizeof(float), static_cast<hipStream_t>(stream),
-                       in, out, (int)C, (int)W, (int)r, (int)tiles_w);
+    hipLaunchKernelGGL(sample_shuffle_kernel<T>, dim3((unsigned)blocks), dim3(256), (size_t)r * (SHUF_TW + 1) * sizeof(T),
+                       static_cast<hipStream_t>(stream), static_cast<const T*>(in), static_cast<T*>(out), (int)C, (int)W, (int)r,
+                       (int)tiles_w);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+}  // namespace
+
+extern "C" int stof_sample_shuffle_bytes(const void* in, void* out, int64_t N, int64_t C_in, int64_t W, int32_t r,
+                                         int32_t elem_bytes, void* stream) {
+    if (N < 0 || C_in < 0 || W < 0 || r < 1) return STOF_ERR_BAD_ARG;
+    if (C_in % r != 0) return STOF_ERR_CHANNELS;
+    if (N == 0 || C_in == 0 || W == 0) return STOF_OK;
+    if (!in || !out) return STOF_ERR_BAD_ARG;
+    if (r > 128 || (elem_bytes == 16 && r > 32)) return STOF_ERR_UNSUPPORTED;      // the [r][257] LDS tile
+    switch (elem_bytes) {
+    case 1: return launch_shuffle<unsigned char>(in, out, N, C_in, W, r, stream);
+    case 2: return launch_shuffle<unsigned short>(in, out, N, C_in, W, r, stream);
+    case 4: return launch_shuffle<unsigned int>(in, out, N, C_in, W, r, stream);
+    case 8: return launch_shuffle<unsigned long long>(in, out, N, C_in, W, r, stream);
+    case 16: return launch_shuffle<shuf_u128>(in, out, N, C_in, W, r, stream);
+    default: return STOF_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int stof_sample_shuffle(const float* in, float* out, int64_t N, int64_t C_in, int64_t W, int32_t r,
+                                   void* stream) {
+    return stof_sample_shuffle_bytes(in, out, N, C_in, W, r, 4, stream);
 }
 
 extern "C" int stof_pick_maxima(const float* scores, int64_t N, int64_t M, int32_t window_size,

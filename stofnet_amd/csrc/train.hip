@@ -1232,61 +1232,94 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 }
 
 // dW1[ch][d] += sum_t g'[t][ch] x[t+d-4], db1[ch] += sum_t g'[t][ch], g' = g * relu'(saved conv1 output)
-constexpr int C1_COPIES = 64;
+// A fixed grid of <= C1_COPIES work-groups walks the row chunks in a fixed assignment (chunk c -> work-group c mod grid), every
+// work-group keeps its sums in registers and writes ONE partial; the partials are added in a fixed order: no float atomics, so
+// the gradient is bitwise repeatable like every other weight gradient of the step (r3 used atomics into 64 replicated copies).
+constexpr int C1_COPIES = 256;
+constexpr int C1_CHUNK = 256;          // rows per chunk
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                           const float* __restrict__ saved,
-                                                          float* __restrict__ copies, int N, int L, int rows_per_block) {
+                                                          float* __restrict__ copies, int N, int L) {
     __shared__ float red[4][64][10];
     // (part -- hence the row and its nine input samples -- is wave-uniform: made scalar so that the samples come through the
     // scalar cache; as vector loads they were nine of the eleven loads per row and the texture addresser was the limit, 149 us)
     const int tid = threadIdx.x, ch = tid & 63, part = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r0 = blockIdx.x * rows_per_block;                 // N*L < 2^31 is checked by the caller
-    const int total = N * L;
+    const int total = N * L;                                    // N*L < 2^31 is checked by the caller
     float acc[10];
 #pragma unroll
     for (int d = 0; d < 10; ++d) acc[d] = 0.f;
-    const int rend = min(r0 + rows_per_block, total);
-    int t = (r0 + part) % L;
+    for (int r0 = blockIdx.x * C1_CHUNK; r0 < total; r0 += gridDim.x * C1_CHUNK) {
+        const int rend = min(r0 + C1_CHUNK, total);
+        int t = (r0 + part) % L;
 #pragma unroll 4
-    for (int r = r0 + part; r < rend; r += 4) {
-        const float* xr = x + (r - t);
-        const float gl = g[(size_t)r * 64 + ch], sl = saved[(size_t)r * 64 + ch];      // (both requested before either is used)
-        const float gv = sl > 0.f ? gl : 0.f;
-        float xv[9];
-        if (t >= 4 && t < L - 4) {                              // (scalar: all nine samples inside the waveform, no guards)
+        for (int r = r0 + part; r < rend; r += 4) {
+            const float* xr = x + (r - t);
+            const float gl = g[(size_t)r * 64 + ch], sl = saved[(size_t)r * 64 + ch];      // (both requested before either is used)
+            const float gv = sl > 0.f ? gl : 0.f;
+            float xv[9];
+            if (t >= 4 && t < L - 4) {                              // (scalar: all nine samples inside the waveform, no guards)
 #pragma unroll
-            for (int d = 0; d < 9; ++d) xv[d] = xr[t + d - 4];
-        } else {
+                for (int d = 0; d < 9; ++d) xv[d] = xr[t + d - 4];
+            } else {
 #pragma unroll
-            for (int d = 0; d < 9; ++d) { const int u = t + d - 4; xv[d] = (u >= 0 && u < L) ? xr[u] : 0.f; }
+                for (int d = 0; d < 9; ++d) { const int u = t + d - 4; xv[d] = (u >= 0 && u < L) ? xr[u] : 0.f; }
+            }
+#pragma unroll
+            for (int d = 0; d < 9; ++d) acc[d] = fmaf(gv, xv[d], acc[d]);
+            acc[9] += gv;
+            t += 4;
+            while (t >= L) t -= L;                                  // (L < 4: more than one wrap)
         }
-#pragma unroll
-        for (int d = 0; d < 9; ++d) acc[d] = fmaf(gv, xv[d], acc[d]);
-        acc[9] += gv;
-        t += 4;
-        if (t >= L) t -= L;
     }
 #pragma unroll
     for (int d = 0; d < 10; ++d) red[part][ch][d] = acc[d];
     __syncthreads();
     if (part == 0) {
-        float* copy = copies + (blockIdx.x % C1_COPIES) * 640;       // spread the atomics over replicated accumulators
+        float* copy = copies + blockIdx.x * 640;
 #pragma unroll
-        for (int d = 0; d < 10; ++d) {
-            const float s = (red[0][ch][d] + red[1][ch][d]) + (red[2][ch][d] + red[3][ch][d]);
-            atomicAdd(copy + ch * 10 + d, s);
-        }
+        for (int d = 0; d < 10; ++d) copy[ch * 10 + d] = (red[0][ch][d] + red[1][ch][d]) + (red[2][ch][d] + red[3][ch][d]);
     }
 }
 
-__global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ copies, float* __restrict__ dw, float* __restrict__ db,
+__global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ copies, int ncopies, float* __restrict__ dw, float* __restrict__ db,
                                           float out_scale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (ch, d)
     if (i >= 640) return;
     float s = 0.f;
-    for (int c = 0; c < C1_COPIES; ++c) s += copies[c * 640 + i];
+    for (int c = 0; c < ncopies; ++c) s += copies[c * 640 + i];
     const int ch = i / 10, d = i - ch * 10;
     if (d < 9) dw[ch * 9 + d] = s * out_scale; else db[ch] = s * out_scale;
+}
+
+// Gradient with respect to the input frame (models/stofnet.py:45 differentiated: the reference's autograd provides it for free):
+// dx[n][u] = out_scale * sum_d sum_ch w1[ch][d] g'[n][u + 4 - d][ch],  g' = g * relu'(saved conv1 output).  One thread per sample;
+// the nine rows of g' it reads are shared with its neighbours through the caches; off the hot path (nobody trains the input).
+__global__ __launch_bounds__(256) void conv1_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ saved,
+                                                          const float* __restrict__ w, float* __restrict__ dx, int N, int L,
+                                                          float out_scale) {
+    __shared__ float ws[9][64];                                   // [tap][channel]
+    for (int i = threadIdx.x; i < 576; i += 256) ws[i % 9][i / 9] = w[i];
+    __syncthreads();
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= (long long)N * L) return;
+    const int u = (int)(i % L);
+    const long long n = i / L;
+    float acc = 0.f;
+    for (int d = 0; d < 9; ++d) {
+        const int t = u + 4 - d;
+        if (t < 0 || t >= L) continue;
+        const float4* gr = reinterpret_cast<const float4*>(g + ((size_t)n * L + t) * 64);
+        const float4* sr = reinterpret_cast<const float4*>(saved + ((size_t)n * L + t) * 64);
+#pragma unroll 4
+        for (int c4 = 0; c4 < 16; ++c4) {
+            const float4 gv = gr[c4], sv = sr[c4];
+            acc = fmaf(sv.x > 0.f ? gv.x : 0.f, ws[d][4 * c4], acc);
+            acc = fmaf(sv.y > 0.f ? gv.y : 0.f, ws[d][4 * c4 + 1], acc);
+            acc = fmaf(sv.z > 0.f ? gv.z : 0.f, ws[d][4 * c4 + 2], acc);
+            acc = fmaf(sv.w > 0.f ? gv.w : 0.f, ws[d][4 * c4 + 3], acc);
+        }
+    }
+    dx[i] = acc * out_scale;
 }
 
 // MaxPool1d(S, S) (S = sample_scale, 80 in every shipped checkpoint) over time of c[N][L][C] -> pooled[N][P][C] with the arg-max offset (first maximum)
@@ -1653,11 +1686,21 @@ extern "C" int stof_train_conv1_wgrad(const float* x, const float* g, const floa
     if (workspace_bytes < stof_train_conv1_wgrad_workspace_bytes()) return STOF_ERR_WORKSPACE;
     if (N * L > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
     float* copies = static_cast<float*>(workspace);
-    if (hipMemsetAsync(copies, 0, stof_train_conv1_wgrad_workspace_bytes(), s) != hipSuccess) return STOF_ERR_HIP;
-    const int rows_per_block = 256;
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)((N * L + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s,
-                       x, g, saved, copies, (int)N, (int)L, rows_per_block);
-    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(3), dim3(256), 0, s, copies, dw, db, out_scale);
+    const int64_t chunks = (N * L + C1_CHUNK - 1) / C1_CHUNK;
+    const int grid = (int)(chunks < C1_COPIES ? chunks : C1_COPIES);
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, g, saved, copies, (int)N, (int)L);
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(3), dim3(256), 0, s, copies, grid, dw, db, out_scale);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_conv1_dgrad(const float* g, const float* saved, const float* w, float* dx, int64_t N, int64_t L,
+                                      float out_scale, void* stream) {
+    if (N < 0 || L < 0) return STOF_ERR_BAD_ARG;
+    if (N == 0 || L == 0) return STOF_OK;
+    if (!g || !saved || !w || !dx) return STOF_ERR_BAD_ARG;
+    if (N * L > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv1_dgrad_kernel, dim3((unsigned)((N * L + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       g, saved, w, dx, (int)N, (int)L, out_scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

@@ -7,7 +7,10 @@ import torch
 
 from . import _lib
 
-_IDX_CAP = 32            # detections per row kept by the first pass; larger rows trigger a re-run
+_IDX_CAP = 32            # detections per row kept by the first pass of arg-max mode (Kmax = 1 barring ties)
+_TH_CAP = 128            # ... of threshold mode, where Kmax is data dependent (PALA, th = .015: mean 46, max 79 per row)
+_last_kmax = {}          # (threshold mode?) -> Kmax of the previous call: the next call's first pass is sized for it, so a
+                         # steady stream of similar batches (main.py:320 in an evaluation loop) takes ONE pass per call
 
 
 def _pick(scores: torch.Tensor, window_size: int, threshold, cap: int, counts=None, idx=None):
@@ -33,10 +36,13 @@ def _pick(scores: torch.Tensor, window_size: int, threshold, cap: int, counts=No
 
 
 def _pick_all(scores, window_size, threshold):
-    s, counts, idx = _pick(scores, window_size, threshold, _IDX_CAP)
+    mode = bool(threshold)
+    cap = max(_TH_CAP if mode else _IDX_CAP, min(_last_kmax.get(mode, 0) * 5 // 4, 4096))
+    s, counts, idx = _pick(scores, window_size, threshold, cap)
     kmax = int(counts.max()) if counts.numel() else 0   # host sync, as utils/mask2samples.py:93
-    if kmax > idx.shape[1]:
+    if kmax > idx.shape[1]:                             # a row with more detections than the first pass kept: once more
         s, counts, idx = _pick(scores, window_size, threshold, kmax)
+    _last_kmax[mode] = kmax
     return s, counts, idx, kmax
 
 

@@ -12,12 +12,14 @@ def sample_shuffle(x: torch.Tensor, upsample_factor: int) -> torch.Tensor:
     if cin % r != 0:
         # the reference's .view raises RuntimeError (utils/sample_shuffle.py:24)
         raise RuntimeError(f"shape '[{n}, {r}, {cin // r}, {w}]' is invalid for input of size {x.numel()}")
-    xc = x.contiguous().float()
-    out = torch.empty((n, cin // r, w * r), dtype=torch.float32, device=x.device)
+    # a pure permutation of elements (utils/sample_shuffle.py:24-27: view / permute / contiguous): every dtype goes through the
+    # kernel bit for bit by its element size -- int64 ramps beyond 2^24, float64, float16, bool, complex alike
+    xc = x.contiguous()
+    out = torch.empty((n, cin // r, w * r), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().stof_sample_shuffle(_lib.ptr(xc), _lib.ptr(out), n, cin, w, r,
-                                                  _lib.stream_ptr(x.device)), 'stof_sample_shuffle')
-    return out.to(x.dtype)
+        _lib.check(_lib.lib().stof_sample_shuffle_bytes(_lib.ptr(xc), _lib.ptr(out), n, cin, w, r, x.element_size(),
+                                                        _lib.stream_ptr(x.device)), 'stof_sample_shuffle')
+    return out
 
 
 class _ShuffleFn(torch.autograd.Function):

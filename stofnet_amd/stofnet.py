@@ -172,7 +172,8 @@ class StofNet(nn.Module):
             raise RuntimeError(f'expected input [N, {self.in_channels}, L], got {list(x.shape)}')
         n, _, L = x.shape
         r = int(self.upsample_factor)
-        if self.training and torch.is_grad_enabled() and _events is None and any(p.requires_grad for p in self.parameters()):
+        if (torch.is_grad_enabled() and _events is None and
+                ((self.training and any(p.requires_grad for p in self.parameters())) or x.requires_grad)):
             return self._forward_with_graph(x)
         if not self._fused_sweep():
             return self._forward_layerwise(x)
@@ -238,9 +239,6 @@ class StofNet(nn.Module):
         """Train-mode forward (main.py:221): same numbers as the inference path to fp32 rounding, but every layer's
         activation is kept and the result carries a grad_fn whose backward fills the parameters' gradients."""
         from .training import StofNetFunction
-        if x.requires_grad:
-            raise NotImplementedError('StofNet: the gradient with respect to the input frame is not implemented '
-                                      '(the reference trains the parameters only); pass x.detach()')
         if x.shape[0] == 0:
             raise RuntimeError('StofNet: empty batch in train mode')
         named = list(self.named_parameters())

@@ -162,7 +162,7 @@ class TrainEngine:
             ys = [t[1 + 2 * k] for k in range(5)]
             saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=t[11], bwd=bwd, n=n, L=L, P=P, rem=rem,
                          _dump=dump, desc=desc, wdev=[p[f'conv{i}.weight'] for i in range(2, 13)],
-                         wc=p.get(sg + 'contract_conv.weight'), wl=p['conv_last.weight'])
+                         wc=p.get(sg + 'contract_conv.weight'), wl=p['conv_last.weight'], w1=p['conv1.weight'])
             return z, saved
         if self.sgb:
             x0, c, pooled, arg, e = self._sgb_forward(a1, fwd[sg + 'contract_conv'], p[sg + 'contract_conv.bias'],
@@ -185,7 +185,7 @@ class TrainEngine:
         if not keep:
             return z.view(n, L * r), None
         saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=x6, bwd=bwd, n=n, L=L, P=P, rem=rem,
-                     wc=p.get('semi_global_block.contract_conv.weight'), wl=p['conv_last.weight'])
+                     wc=p.get('semi_global_block.contract_conv.weight'), wl=p['conv_last.weight'], w1=p['conv1.weight'])
         return z.view(n, L * r), saved
 
     def _sgb_head(self, a1, w_contract, b_contract, w_expand, b_expand):
@@ -215,10 +215,11 @@ class TrainEngine:
                    'stof_train_upsample_add')
         return out, c, pooled, arg, e
 
-    def _backward_saved(self, saved, dpred, g, gscale):
+    def _backward_saved(self, saved, dpred, g, gscale, dx=None):
         """Backward pass from dpred [N, L*r] = gscale * dloss/dpred (gscale a power of two: the f16x3 data-gradient
         convolutions would otherwise work on fp16 subnormals; the weight-gradient kernels multiply by 1/gscale, exact).
-        Writes every parameter gradient into the tensors of `g` (name -> tensor of the parameter's shape)."""
+        Writes every parameter gradient into the tensors of `g` (name -> tensor of the parameter's shape) and, if `dx`
+        [N, L] is given, the gradient with respect to the input frame into it."""
         lib = _lib.lib()
         r, st = self.r, self._st()
         sg = 'semi_global_block.'
@@ -312,6 +313,10 @@ class TrainEngine:
         _lib.check(lib.stof_train_conv1_wgrad(_lib.ptr(saved['x']), _lib.ptr(g_a1), _lib.ptr(a1), _lib.ptr(g['conv1.weight']),
                                               _lib.ptr(g['conv1.bias']), n, L, 1.0 / self._gscale, _lib.ptr(ws1),
                                               ws1.numel(), st), 'stof_train_conv1_wgrad')
+        if dx is not None:
+            # d loss / d frame (the reference's autograd yields it for free, models/stofnet.py:45): conv1 transposed on the masked gradient
+            _lib.check(lib.stof_train_conv1_dgrad(_lib.ptr(g_a1), _lib.ptr(a1), _lib.ptr(saved['w1'].contiguous()), _lib.ptr(dx),
+                                                  n, L, 1.0 / self._gscale, st), 'stof_train_conv1_dgrad')
 
 
 class StofNetFunction(torch.autograd.Function):
@@ -319,7 +324,7 @@ class StofNetFunction(torch.autograd.Function):
     `backward()` runs the `stof_train_*` data- and weight-gradient kernels and hands torch the gradient of every
     `nn.Parameter`, so the reference's own lines -- torch loss (main.py:228-232), `optimizer.zero_grad();
     loss.backward(); optimizer.step()` with `optim.AdamW` and `CosineAnnealingLR` (main.py:179-180,246-248,288) -- run
-    unchanged.  The gradient with respect to the input frame is not provided (the reference never asks for it)."""
+    unchanged.  The gradient with respect to the input frame is provided too when `frame.requires_grad`."""
 
     @staticmethod
     def forward(ctx, frame, engine, names, *params):
@@ -346,6 +351,9 @@ class StofNetFunction(torch.autograd.Function):
                 # convolutions.  Scale by the power of two that brings the largest entry to [1, 2) (exact); the
                 # weight-gradient kernels multiply by 1/scale (exact).  One host read per step.
                 amax = float(dpred.abs().amax())
+                if not math.isfinite(amax):
+                    raise FloatingPointError("StofNet(train_precision='f16x3'): non-finite dloss/dpred (an activation left the fp16 "
+                                             "range of the split-fp16 arithmetic?); train with train_precision='fp32'")
                 if amax > 0.0 and math.isfinite(amax):
                     gscale = 2.0 ** (-math.floor(math.log2(amax)))
                     dpred = dpred * gscale
@@ -355,9 +363,16 @@ class StofNetFunction(torch.autograd.Function):
             for name, sh, k in zip(ctx.names, ctx.shapes, sizes):
                 g[name] = flat[off:off + k].view(sh)
                 off += k
-            engine._backward_saved(saved, dpred, g, gscale)
+            dx = None
+            if ctx.needs_input_grad[0]:                 # d loss / d frame: the reference's autograd yields it (models/stofnet.py:45)
+                dx = torch.empty((n, saved['L']), dtype=torch.float32, device=engine.dev)
+            engine._backward_saved(saved, dpred, g, gscale, dx)
+            if engine.prec == 1 and not bool(torch.isfinite(flat).all()):      # range guard of the split-fp16 backward (one more host read)
+                ctx.saved = None
+                raise FloatingPointError("StofNet(train_precision='f16x3'): a back-propagated value left the fp16 range (non-finite "
+                                         "gradient); train with train_precision='fp32'")
         ctx.saved = None
-        return (None, None, None) + tuple(g[name] for name in ctx.names)
+        return (None if dx is None else dx.view(n, 1, saved['L']), None, None) + tuple(g[name] for name in ctx.names)
 
 
 class StofNetTrainer(TrainEngine):
@@ -379,6 +394,7 @@ class StofNetTrainer(TrainEngine):
         self.lam, self.amp = float(lambda_value), float(mask_amplitude)
         self.group = process_group
         self.target_max_hook = None      # tests: stands in for the MAX all-reduce of the blurred-target maximum
+        self.overflow_flag = None        # sticky device word of the split-fp16 range guard (_guard_grads)
         self.step_count = 0
         dev = self.dev
         _lib.require_device(params[0][1], 'model parameters')
@@ -451,6 +467,27 @@ class StofNetTrainer(TrainEngine):
         GPU node; one 2.58 MB all-reduce per step, latency-bound)."""
         allreduce_mean_(self.flat_grad, self.group)
 
+    def _guard_grads(self, loss=None):
+        """Range guard of the split-fp16 training arithmetic (the reference trains in plain fp32): an activation or a
+        back-propagated value beyond the fp16 range turns into inf / NaN and would reach every weight through AdamW.  On the
+        device, without a host read: if the loss or any gradient is non-finite the whole gradient bucket is zeroed (this step
+        becomes a no-op for the weights apart from weight decay) and a sticky flag is set; `raise_if_overflow()` reads it."""
+        ok = torch.isfinite(self.flat_grad).all()
+        if loss is not None:
+            ok = ok & torch.isfinite(loss).all()
+        self.flat_grad.copy_(torch.where(ok, self.flat_grad, torch.zeros((), dtype=torch.float32, device=self.dev)))
+        bad = (~ok).to(torch.int32).reshape(1)
+        self.overflow_flag = bad if self.overflow_flag is None else torch.maximum(self.overflow_flag, bad)
+
+    def raise_if_overflow(self):
+        """One host read: raises FloatingPointError if any step since the last check left the fp16 range (its update was
+        skipped); use precision='fp32' for such data."""
+        if self.overflow_flag is not None and int(self.overflow_flag.item()) != 0:
+            self.overflow_flag.zero_()
+            raise FloatingPointError(f"StofNetTrainer(precision='{'f16x3' if self.prec == 1 else 'fp32'}'): a loss or gradient was "
+                                     "non-finite (fp16 range overflow of the split-fp16 arithmetic); those steps were skipped -- "
+                                     "train with precision='fp32'")
+
     def step(self):
         self.step_count += 1
         with torch.cuda.device(self.dev):
@@ -462,8 +499,10 @@ class StofNetTrainer(TrainEngine):
 
     def train_step(self, frame, gt_true):
         loss, pred = self.forward_backward(frame, gt_true)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if _collectives_on(self.group):
             self.allreduce_grads()
+        if self.prec == 1:                 # split-fp16: device-side range guard (after the all-reduce: every rank decides alike)
+            self._guard_grads(loss)
         self.step()
         return loss, pred
 
@@ -472,18 +511,26 @@ class StofNetTrainer(TrainEngine):
         self.lr = 0.5 * base_lr * (1.0 + math.cos(math.pi * epoch / epochs))
 
 
+def _collectives_on(group=None) -> bool:
+    """A process group of more than one rank -- or of one rank with STOF_FORCE_COLLECTIVES=1, which lets a one-GPU box
+    exercise the RCCL calls themselves (tests/test_rccl_one_rank.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get('STOF_FORCE_COLLECTIVES') == '1'
+
+
 def allreduce_max_(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place MAX all-reduce (the batch-global maximum of the blurred target, main.py:230)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collectives_on(group):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return t
 
 
 def allreduce_mean_(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
     """In-place mean all-reduce of a flat gradient bucket (works on any backend: nccl = RCCL, gloo in tests)."""
-    if dist.is_available() and dist.is_initialized():
+    if _collectives_on(group):
         world = dist.get_world_size(group)
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
         if world > 1:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
             flat_grad.div_(world)
     return flat_grad

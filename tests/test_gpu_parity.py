@@ -335,6 +335,32 @@ def test_shuffle_against_oracle_large(dev, r, C, W, N):
     assert torch.equal(out, so.sample_shuffle(x, r))
 
 
+@pytest.mark.parametrize('dtype', [torch.int64, torch.float64, torch.float16, torch.bfloat16, torch.int16, torch.uint8, torch.bool,
+                                   torch.complex64, torch.complex128, torch.int32])
+def test_shuffle_is_dtype_agnostic_bit_for_bit(dev, dtype):
+    """utils/sample_shuffle.py:24-27 is view / permute / contiguous: any dtype, no arithmetic.  int64 ramps beyond 2^24 (which a
+    detour through fp32 would round), float64, the 16-bit floats, bool and the complex types come back bit for bit, dtype kept."""
+    from stofnet_amd import SampleShuffle1D
+    n, r, c, w = 3, 5, 2, 301
+    g = torch.Generator().manual_seed(11)
+    if dtype == torch.bool:
+        x = torch.randint(0, 2, (n, r * c, w), generator=g).bool()
+    elif dtype.is_complex:
+        x = torch.complex(torch.randn(n, r * c, w, generator=g, dtype=torch.float64), torch.randn(n, r * c, w, generator=g, dtype=torch.float64)).to(dtype)
+    elif dtype.is_floating_point:
+        x = (torch.randn(n, r * c, w, generator=g, dtype=torch.float64) * 1e3).to(dtype)
+    elif dtype == torch.uint8:
+        x = torch.randint(0, 256, (n, r * c, w), generator=g).to(dtype)
+    else:
+        hi = min(torch.iinfo(dtype).max, 2 ** 62)
+        x = (torch.arange(n * r * c * w, dtype=torch.int64).reshape(n, r * c, w) * 7919 + (2 ** 40 if dtype == torch.int64 else 0)) % hi
+        x = x.to(dtype)
+    out = SampleShuffle1D(r)(x.to(dev))
+    want = so.sample_shuffle(x, r)
+    assert out.dtype == dtype and out.shape == want.shape
+    assert torch.equal(out.cpu().view(torch.uint8) if dtype != torch.bool else out.cpu(), want.view(torch.uint8) if dtype != torch.bool else want)
+
+
 def test_shuffle_roundtrip_property_full_size(dev):
     """C3 size [4096,20,2000] -> [4096,1,40000]: the shuffle is a permutation, so sums of
     every k-strided slice must equal the channel sums."""

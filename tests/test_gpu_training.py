@@ -320,11 +320,45 @@ def test_autograd_boundary_semantics(dev):
                 ref[n] = p.grad.clone()
             else:
                 assert float((p.grad - ref[n]).abs().max()) < 2e-3 * float(ref[n].abs().max()), n
-    with pytest.raises(NotImplementedError):
-        m(x.clone().requires_grad_())
     for p in m.parameters():
         p.requires_grad_(False)
     assert not m(x).requires_grad                                    # nothing to train: plain inference path
+
+
+@pytest.mark.parametrize('tp,tol', [('fp32', 2e-4), ('f16x3', 2e-3)])
+@pytest.mark.parametrize('sgs', [80, 1])
+def test_input_gradient_matches_autograd(dev, tp, tol, sgs):
+    """d loss / d frame, which the reference's autograd yields for free (models/stofnet.py:42-67 is differentiable end to end):
+    `x.requires_grad_()` -> `x.grad` after backward, against float64 autograd through the oracle; also in eval mode with the
+    parameters frozen (saliency-style use), and together with the parameter gradients."""
+    from oracle import stofnet_oracle as so
+    from stofnet_amd import StofNet
+    r, L, n = 4, 400, 3
+    sd = synth.synth_state_dict(r, seed=21, semi_global_scale=sgs)
+    x_np = synth.synth_echo(n, L, seed=4)
+    m = StofNet(upsample_factor=r, semi_global_scale=sgs, train_precision=tp)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(dev).train()
+    x = torch.from_numpy(x_np).to(dev).requires_grad_()
+    g = torch.Generator().manual_seed(5)
+    wgt = torch.randn(n, 1, L * r, generator=g)
+    (m(x) * wgt.to(dev)).sum().backward()
+    # oracle, float64
+    p64 = {k: torch.tensor(v, dtype=torch.float64) for k, v in sd.items()}
+    x64 = torch.tensor(x_np, dtype=torch.float64, requires_grad=True)
+    (so.stofnet_forward(p64, x64, r, sgs, torch.float64) * wgt.double()).sum().backward()
+    ref = x64.grad
+    assert x.grad is not None and x.grad.shape == x.shape
+    err = float((x.grad.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < tol, err
+    assert all(p.grad is not None for p in m.parameters())          # the parameter gradients came along
+    # frozen parameters, eval mode: still a gradient with respect to the frame
+    m.eval()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    x2 = torch.from_numpy(x_np).to(dev).requires_grad_()
+    (m(x2) * wgt.to(dev)).sum().backward()
+    assert float((x2.grad.cpu().double() - ref).abs().max() / ref.abs().max()) < tol
 
 
 def test_main_entry_point_trains_through_the_autograd_boundary(dev, tmp_path):
@@ -456,3 +490,39 @@ def test_ddp_shards_with_different_target_maxima_match_full_batch(dev):
     scale = np.abs(g_full).max()
     assert np.abs(0.5 * (fixed[0] + fixed[1]) - g_full).max() < 1e-5 * scale
     assert np.abs(0.5 * (local[0] + local[1]) - g_full).max() > 1e-3 * scale      # the bug this guards against
+
+
+def test_split_fp16_training_range_guard(dev):
+    """the split-fp16 training kernels have no fp32 re-run, so an activation beyond the fp16 range (65504) must not
+    reach the weights.  Fused trainer: the step is skipped on the device (weights stay finite) and raise_if_overflow() reports it;
+    autograd boundary: backward raises FloatingPointError.  fp32 training of the same input works."""
+    from stofnet_amd import StofNet
+    from stofnet_amd.training import StofNetTrainer
+    r, L, n = 4, 400, 4
+    sd = synth.synth_state_dict(r, seed=3)
+    sd = {k: (v * (40.0 if k.endswith('conv1.weight') else 1.0)).astype(np.float32) for k, v in sd.items()}
+    x = torch.from_numpy(synth.synth_echo(n, L, seed=2) * 3.0e3).to(dev)           # relu(conv1) ~ 1e5 and growing: beyond fp16
+    gt = torch.randint(1, L * r, (n, 1, 2), generator=torch.Generator().manual_seed(1)).sort(-1).values.to(dev)
+
+    def build(tp):
+        m = StofNet(upsample_factor=r, train_precision=tp)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        return m.to(dev)
+
+    m = build('f16x3')
+    tr = StofNetTrainer(m, precision='f16x3')
+    before = tr.flat.clone()
+    tr.train_step(x, gt)
+    assert bool(torch.isfinite(tr.flat).all())                                     # no NaN reached the weights
+    assert float((tr.flat - before).abs().max()) < 1e-6                            # the update was skipped (weight decay 1e-8 aside)
+    with pytest.raises(FloatingPointError):
+        tr.raise_if_overflow()
+    tr.raise_if_overflow()                                                         # the sticky word was cleared by the read
+    m2 = build('f16x3').train()
+    with pytest.raises(FloatingPointError):
+        (m2(x) ** 2).mean().backward()
+    m3 = build('fp32')
+    tr3 = StofNetTrainer(m3, precision='fp32')
+    loss, _ = tr3.train_step(x, gt)
+    assert np.isfinite(float(loss)) and bool(torch.isfinite(tr3.flat).all())
+    tr3.raise_if_overflow()
