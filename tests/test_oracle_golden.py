@@ -355,3 +355,26 @@ def test_pala_gradpeak_oracle_end_to_end():
         peaks = po.gradpeak_forward(x, th, 20, float('inf'), False, env=env)
         onsets = po.gradpeak_forward(x, th, 20, float('inf'), True, env=env)
         assert np.array_equal(peaks, g[f'peaks_th{thn}']) and np.array_equal(onsets, g[f'onsets_th{thn}'])
+
+
+@pytest.mark.parametrize('rf', [10, 20])
+@pytest.mark.parametrize('tag,th', [('th1e-3', 1e-3), ('thdef', None)])
+def test_gradpeak_oracle_matches_reference_on_4096_rows(rf, tag, th):
+    """f9_gradpeak_4096 (make_golden_r4.py): the float64 oracle and the reference's fp32 toa_detect pick the same onset / peak
+    samples on every one of the 4096 rows (so the GPU test may demand the same)."""
+    from stofnet_amd import synth
+    g = np.load(os.path.join(GOLDEN, 'f9_gradpeak_4096.npz'))
+    if rf == 20 and th is None:
+        rows = 1024                       # the default-threshold case at rf 20 walks 18 echoes per row: bound the CPU time
+    else:
+        rows = 2048
+    x = synth.synth_echo(int(g['rows']), int(g['L']), seed=int(g['seed']), noise=float(g['noise']))[:, 0]
+    ref = g[f'rf{rf}_{tag}']
+    if th is None:
+        got = po.toa_detect(x, th, rf)    # the default threshold is a statistic of the WHOLE batch: all rows go in
+        rows = x.shape[0]
+    else:
+        got = po.toa_detect(x[:rows], th, rf)
+    k = max(got.shape[1], ref.shape[1])
+    pad = lambda a: np.pad(a, ((0, 0), (0, k - a.shape[1]), (0, 0)))
+    assert np.array_equal(pad(got)[..., :2], pad(ref[:rows])[..., :2])
