@@ -293,6 +293,13 @@ size_t stof_train_wgrad_workspace_bytes(int32_t cin, int32_t cout, int32_t K);
 int stof_train_wgrad(const float* x, const float* dy, float* dw, float* db, int64_t N, int64_t L,
                      int32_t cin, int32_t cout, int32_t K, float out_scale, int32_t precision, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* r4: the weight / bias gradients of `count` (<= 12) 64 -> 64 layers of kernel size K in ONE launch pair (split-fp16 arithmetic):
+ * the eleven k7 layers of the body (models/stofnet.py:31) in the training step.  x[i], dy[i] channel-last [N][L][64];
+ * dw[i] (64,64,K), db[i] (64) are overwritten; partial sums are added in a fixed order (bitwise reproducible).          */
+size_t stof_train_wgrad_batch_workspace_bytes(int32_t count, int32_t K);
+int stof_train_wgrad_batch(const float* const* x, const float* const* dy, float* const* dw, float* const* db, int32_t count,
+                           int64_t N, int64_t L, int32_t K, float out_scale, void* workspace, size_t workspace_bytes,
+                           void* stream);
 /* conv1 (1->64, k9) + ReLU forward to channel-last, and its weight gradient (g masked by relu').    */
 int stof_train_conv1(const float* x, const float* w, const float* b, float* y, int64_t N, int64_t L, void* stream);
 size_t stof_train_conv1_wgrad_workspace_bytes(void);

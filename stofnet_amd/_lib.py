@@ -106,6 +106,9 @@ _SIGNATURES = {
     'stof_train_conv1': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
     'stof_train_conv1_wgrad_workspace_bytes': (_c.c_size_t, []),
     'stof_train_conv1_wgrad': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    'stof_train_wgrad_batch_workspace_bytes': (_c.c_size_t, [_c.c_int32, _c.c_int32]),
+    'stof_train_wgrad_batch': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_int64, _c.c_int32,
+                                          _c.c_float, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     'stof_train_conv1_dgrad': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_void_p]),
     'stof_train_sweep_blob_bytes': (_c.c_size_t, [_c.c_void_p]),
     'stof_train_sweep_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),

@@ -643,13 +643,13 @@ __device__ __forceinline__ uint2 tr_read(const char* p) {
     __builtin_memcpy(&u, &r, 8);
     return u;
 }
+// (gx, G) = this work-group's index among the G persistent groups of its weight block; (o0, c0) = the block; cz = its c index
 template <int KMAX>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradParams p) {
+__device__ __forceinline__ void conv_wgrad_f16x3_body(const WgradParams& p, const int gx, const int G, const int o0, const int c0, const int cz) {
     __shared__ __attribute__((aligned(16))) char dys[WG_ROWS_H * HSTRIDE];
     __shared__ __attribute__((aligned(16))) char xs[(WG_ROWS_H + 8) * HSTRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mi = wave & 1, ni = wave >> 1, ln = lane & 31, lh = lane >> 5;
-    const int o0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
     const int K = p.K, pad = K >> 1;
     floatx16 acc[KMAX];
 #pragma unroll
@@ -701,8 +701,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradPar
             rx[u] = v;
         }
     };
-    if ((int)blockIdx.x < p.total_tiles) fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+    if (gx < p.total_tiles) fetch(gx);
+    for (int tile = gx; tile < p.total_tiles; tile += G) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NDY; ++u) {
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradPar
             }
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < p.total_tiles) fetch(tile + gridDim.x);
+        if (tile + G < p.total_tiles) fetch(tile + G);
 #pragma unroll
         for (int ks = 0; ks < WG_ROWS_H / 16; ++ks) {
             const char* a = ap + ks * 16 * HSTRIDE;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradPar
         }
     }
     // bias gradient: thread (row lane tid >> 4, column quad tid & 15) holds the sums of its rows; fold the 16 row lanes
-    if (blockIdx.z == 0) {
+    if (cz == 0) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(xs);
         *reinterpret_cast<float4*>(red + (tid >> 4) * 64 + 4 * (tid & 15)) = dbq;
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradPar
             dbs = s;
         }
     }
-    float* part = p.part + (size_t)blockIdx.x * K * p.cout_pad * p.cin_pad;
+    float* part = p.part + (size_t)gx * K * p.cout_pad * p.cin_pad;
     const int c = c0 + 32 * ni + ln;
 #pragma unroll
     for (int d = 0; d < KMAX; ++d) {
@@ -765,15 +765,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradPar
             part[((size_t)d * p.cout_pad + o) * p.cin_pad + c] = acc[d][v];
         }
     }
-    if (blockIdx.z == 0 && tid < 64) p.dbpart[(size_t)blockIdx.x * p.cout_pad + o0 + tid] = dbs;
+    if (cz == 0 && tid < 64) p.dbpart[(size_t)gx * p.cout_pad + o0 + tid] = dbs;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(const WgradParams p) {
+    conv_wgrad_f16x3_body<KMAX>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y * 64, (int)blockIdx.z * 64, (int)blockIdx.z);
+}
+
+// r4: the weight gradients of SEVERAL 64 -> 64 layers in one launch (the eleven k7 layers of StofNet's body: eleven launches of
+// 97 us each + eleven reductions of 58 MB of partials per step in r3).  blockIdx.y = layer; every layer gets G persistent groups,
+// G chosen so that the whole launch is ~2 work-groups per CU: 11 x fewer partials to write and to reduce.
+constexpr int WGRAD_BATCH_MAX = 12;
+struct WgradBatch {
+    const float* x[WGRAD_BATCH_MAX];
+    const float* dy[WGRAD_BATCH_MAX];
+    float* dw[WGRAD_BATCH_MAX];
+    float* db[WGRAD_BATCH_MAX];
+    float* part;               // [count][G][K][64][64]
+    float* dbpart;             // [count][G][64]
+    int N, L, K, tiles_per_wf, total_tiles, count;
+    float out_scale;
+};
+template <int KMAX>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_batch_kernel(const WgradBatch b) {
+    const int layer = blockIdx.y, G = gridDim.x;
+    WgradParams p;
+    p.x = b.x[layer]; p.dy = b.dy[layer];
+    p.part = b.part + (size_t)layer * G * b.K * 64 * 64;
+    p.dbpart = b.dbpart + (size_t)layer * G * 64;
+    p.N = b.N; p.L = b.L; p.cin = 64; p.cout = 64; p.K = b.K; p.tiles_per_wf = b.tiles_per_wf; p.total_tiles = b.total_tiles;
+    p.cin_pad = 64; p.cout_pad = 64;
+    conv_wgrad_f16x3_body<KMAX>(p, (int)blockIdx.x, G, 0, 0, 0);
 }
 
 // dw[o][c][d] = sum_g part[g][d][o][c];  db[o] = sum_g dbpart[g][o]   (fixed summation order).
 // One work-group: 64 consecutive elements x 4 interleaved slices of g, combined through LDS.
 constexpr int WRED_SLICES = 16;                                   // interleaved slices of g per work-group (one wave each)
-__global__ __launch_bounds__(64 * WRED_SLICES) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
-                                                                        float* __restrict__ dw, float* __restrict__ db, int G, int K,
-                                                                        int cout, int cin, int cout_pad, int cin_pad, float out_scale) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, const float* __restrict__ dbpart,
+                                                  float* __restrict__ dw, float* __restrict__ db, int G, int K,
+                                                  int cout, int cin, int cout_pad, int cin_pad, float out_scale) {
     __shared__ float red[WRED_SLICES][64];
     const int per = K * cout_pad * cin_pad;
     const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
@@ -805,6 +836,16 @@ __global__ __launch_bounds__(64 * WRED_SLICES) void wgrad_reduce_kernel(const fl
     } else if (db != nullptr && i - per < cout) {
         db[i - per] = s;
     }
+}
+__global__ __launch_bounds__(64 * WRED_SLICES) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
+                                                                        float* __restrict__ dw, float* __restrict__ db, int G, int K,
+                                                                        int cout, int cin, int cout_pad, int cin_pad, float out_scale) {
+    wgrad_reduce_body(part, dbpart, dw, db, G, K, cout, cin, cout_pad, cin_pad, out_scale);
+}
+__global__ __launch_bounds__(64 * WRED_SLICES) void wgrad_reduce_batch_kernel(const WgradBatch b, int G) {
+    const int layer = blockIdx.y;
+    wgrad_reduce_body(b.part + (size_t)layer * G * b.K * 64 * 64, b.dbpart + (size_t)layer * G * 64, b.dw[layer], b.db[layer], G, b.K,
+                      64, 64, 64, 64, b.out_scale);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1232,10 +1273,10 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 }
 
 // dW1[ch][d] += sum_t g'[t][ch] x[t+d-4], db1[ch] += sum_t g'[t][ch], g' = g * relu'(saved conv1 output)
-// A fixed grid of <= C1_COPIES work-groups walks the row chunks in a fixed assignment (chunk c -> work-group c mod grid), every
+// A grid of <= C1_COPIES work-groups walks the row chunks in a fixed assignment (chunk c -> work-group c mod grid), every
 // work-group keeps its sums in registers and writes ONE partial; the partials are added in a fixed order: no float atomics, so
 // the gradient is bitwise repeatable like every other weight gradient of the step (r3 used atomics into 64 replicated copies).
-constexpr int C1_COPIES = 256;
+constexpr int C1_COPIES = 2048;
 constexpr int C1_CHUNK = 256;          // rows per chunk
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                           const float* __restrict__ saved,
@@ -1281,12 +1322,26 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     }
 }
 
-__global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ copies, int ncopies, float* __restrict__ dw, float* __restrict__ db,
-                                          float out_scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (ch, d)
-    if (i >= 640) return;
+// 640 sums over the partials, in a fixed order: 64 elements x 16 interleaved slices of the copies per work-group (one wave each, four
+// chains per wave so that loads stay in flight), combined through LDS
+__global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float* __restrict__ copies, int ncopies, float* __restrict__ dw,
+                                                                  float* __restrict__ db, float out_scale) {
+    __shared__ float red[16][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + e;                            // (ch, d), 640 in all: 10 work-groups
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int c = q;
+    for (; c + 48 < ncopies; c += 64) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += copies[(size_t)(c + 16 * k) * 640 + i];
+    }
+    for (; c < ncopies; c += 16) a[0] += copies[(size_t)c * 640 + i];
+    red[q][e] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (q != 0) return;
     float s = 0.f;
-    for (int c = 0; c < ncopies; ++c) s += copies[c * 640 + i];
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) s += (red[k][e] + red[k + 1][e]) + (red[k + 2][e] + red[k + 3][e]);
     const int ch = i / 10, d = i - ch * 10;
     if (d < 9) dw[ch * 9 + d] = s * out_scale; else db[ch] = s * out_scale;
 }
@@ -1661,6 +1716,53 @@ extern "C" int stof_train_wgrad(const float* x, const float* dy, float* dw, floa
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
+// groups per layer of the batched launch: ~2 work-groups per CU over the whole launch, at least 8 per layer
+static int wgrad_batch_groups(int count) {
+    const int g = 2 * stof::device_cu_count() / (count < 1 ? 1 : count);
+    return g < 8 ? 8 : g;
+}
+
+extern "C" size_t stof_train_wgrad_batch_workspace_bytes(int32_t count, int32_t K) {
+    if (count < 1 || count > WGRAD_BATCH_MAX || K < 1) return 0;
+    return (size_t)count * wgrad_batch_groups(count) * ((size_t)K * 64 * 64 + 64) * sizeof(float);
+}
+
+extern "C" int stof_train_wgrad_batch(const float* const* x, const float* const* dy, float* const* dw, float* const* db, int32_t count,
+                                      int64_t N, int64_t L, int32_t K, float out_scale, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    if (!x || !dy || !dw || !db || count < 1 || count > WGRAD_BATCH_MAX || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
+    if (K != 7 && K != 5 && K != 3) return STOF_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WgradBatch b;
+    for (int i = 0; i < count; ++i) {
+        if (!dw[i] || !db[i] || ((N > 0 && L > 0) && (!x[i] || !dy[i]))) return STOF_ERR_BAD_ARG;
+        b.x[i] = x[i]; b.dy[i] = dy[i]; b.dw[i] = dw[i]; b.db[i] = db[i];
+    }
+    if (N == 0 || L == 0) {
+        for (int i = 0; i < count; ++i)
+            if (hipMemsetAsync(dw[i], 0, (size_t)64 * 64 * K * sizeof(float), s) != hipSuccess ||
+                hipMemsetAsync(db[i], 0, 64 * sizeof(float), s) != hipSuccess) return STOF_ERR_HIP;
+        return STOF_OK;
+    }
+    if (!workspace || workspace_bytes < stof_train_wgrad_batch_workspace_bytes(count, K)) return STOF_ERR_WORKSPACE;
+    b.N = (int)N; b.L = (int)L; b.K = K; b.count = count; b.out_scale = out_scale;
+    b.tiles_per_wf = (int)((L + WG_ROWS_H - 1) / WG_ROWS_H);
+    const int64_t tiles = N * b.tiles_per_wf;
+    if (tiles > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    b.total_tiles = (int)tiles;
+    int G = wgrad_batch_groups(count);
+    if (G > tiles) G = (int)tiles;
+    b.part = static_cast<float*>(workspace);
+    b.dbpart = b.part + (size_t)count * G * K * 64 * 64;
+    const dim3 grid((unsigned)G, (unsigned)count, 1);
+    if (K == 3) hipLaunchKernelGGL(conv_wgrad_f16x3_batch_kernel<3>, grid, dim3(256), 0, s, b);
+    else if (K == 5) hipLaunchKernelGGL(conv_wgrad_f16x3_batch_kernel<5>, grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(conv_wgrad_f16x3_batch_kernel<7>, grid, dim3(256), 0, s, b);
+    const int total = K * 64 * 64 + 64;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((total + 63) / 64, (unsigned)count), dim3(64 * WRED_SLICES), 0, s, b, G);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
 extern "C" int stof_train_conv1(const float* x, const float* w, const float* b, float* y, int64_t N, int64_t L, void* stream) {
     if (N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     if (N == 0 || L == 0) return STOF_OK;
@@ -1689,7 +1791,7 @@ extern "C" int stof_train_conv1_wgrad(const float* x, const float* g, const floa
     const int64_t chunks = (N * L + C1_CHUNK - 1) / C1_CHUNK;
     const int grid = (int)(chunks < C1_COPIES ? chunks : C1_COPIES);
     hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, g, saved, copies, (int)N, (int)L);
-    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(3), dim3(256), 0, s, copies, grid, dw, db, out_scale);
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(10), dim3(1024), 0, s, copies, grid, dw, db, out_scale);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

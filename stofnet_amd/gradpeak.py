@@ -15,8 +15,10 @@ _CAP = 32          # echoes per row kept by the first pass; rows with more trigg
 # envelope it kept); larger batches run the envelope kernel and the row kernels, which are faster there -- the fused
 # kernels hold a pair of rows per two waves, eight pairs per CU, and every extra round of pairs costs a full
 # transform + streaming latency.  Measured on the MI355X per batch size: tools/time_gradpeak_paths.py ->
-# profiles/r03_gradpeak_paths.json ([2048, 2000]: 69 vs 84 us per call, [4096, 2000]: 92 vs 88, [32768, 2000]: 485 vs 319).
-_ONE_LAUNCH_MAX_ROWS = 3072
+# profiles/r04_gradpeak_paths.json ([2048, 2000]: 67 vs 82 us per call, [4096, 2000]: 91 vs 88, [8192, 2000]: 157 vs 122,
+# [32768, 2000]: 493 vs 321).  r4: the limit includes 4,096 rows (BASELINE config C2's batch): equal time there, and the
+# envelope stays on the chip (1.1x the algorithmic HBM bytes instead of 3.1x).
+_ONE_LAUNCH_MAX_ROWS = 4096
 
 
 def gaussian_kernel_1d(sigma: float, num_sigmas: float = 3.) -> torch.Tensor:

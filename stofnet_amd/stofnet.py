@@ -343,6 +343,16 @@ class StofNet(nn.Module):
             self._status.zero_()
             raise FloatingPointError("StofNet(precision='f16x3'): an activation exceeded the fp16 range; "
                                      "use precision='fp32' for this input")
+        # train_precision='f16x3' behind loss.backward(): a backward since the last check produced a non-finite gradient (that
+        # step's gradients were zeroed on the device).  The next backward makes the same check in the host read it needs anyway.
+        for eng in self._engines.values():
+            word = getattr(eng, '_bwd_overflow', None)
+            if word is not None:
+                eng._bwd_overflow = None
+                if float(word.item()) != 0.0:
+                    raise FloatingPointError("StofNet(train_precision='f16x3'): a backward produced a non-finite gradient (a "
+                                             "back-propagated value left the fp16 range; its gradients were zeroed); train with "
+                                             "train_precision='fp32'")
 
     def _initialize_weights(self):
         """models/stofnet.py:69-77."""

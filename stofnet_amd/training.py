@@ -236,7 +236,10 @@ class TrainEngine:
             g6 = self._conv(dz, bwd['conv_last'], None, r, 64, 3)
         else:
             _lib.check(code, 'stof_train_conv_last_dgrad')
-        self._wgrad(xs[5], g6, 'conv12', 64, 64, 7)
+        batch_wgrad = (self.prec == 1 and saved.get('_dump') is not None and 'conv12' not in bwd
+                       and os.environ.get('STOF_TRAIN_WGRAD_BATCH', '1') != '0')
+        if not batch_wgrad:
+            self._wgrad(xs[5], g6, 'conv12', 64, 64, 7)
         if saved.get('_dump') is not None and 'conv12' not in bwd:
             # the eleven data-gradient convolutions conv12^T .. conv2^T as ONE backward sweep (stof_train_sweep_bwd), then the
             # weight gradients from its dumps: tensor j odd = dL/dx_k, k = (11 - j) / 2; j even = dL/d(pre-activation of conv(12 - j))
@@ -250,9 +253,27 @@ class TrainEngine:
             _lib.check(lib.stof_train_sweep_bwd(ctypes.byref(saved['desc']), _lib.ptr(self._sweep_blob_bwd), _lib.ptr(g6), _lib.ptr(saved['_dump']),
                                                 _lib.ptr(dumpb), n, L, st), 'stof_train_sweep_bwd')
             T = dumpb[:12 * n * L * 64].view(12, n, L, 64)
+            pairs = [(xs[5], g6, 'conv12')] if batch_wgrad else []                      # (input activation, output gradient, layer)
             for k in range(4, -1, -1):
-                self._wgrad(ys[k], T[9 - 2 * k], f'conv{2 * k + 3}', 64, 64, 7)        # g_{k+1} = T[11 - 2 (k + 1)]
-                self._wgrad(xs[k], T[10 - 2 * k], f'conv{2 * k + 2}', 64, 64, 7)       # u_k
+                pairs.append((ys[k], T[9 - 2 * k], f'conv{2 * k + 3}'))                 # g_{k+1} = T[11 - 2 (k + 1)]
+                pairs.append((xs[k], T[10 - 2 * k], f'conv{2 * k + 2}'))                # u_k
+            if batch_wgrad:
+                # r4: the eleven k7 weight gradients in ONE launch pair (stof_train_wgrad_batch) instead of eleven launches +
+                # eleven reductions of 58 MB of partials each
+                import ctypes
+                cnt = len(pairs)
+                need = lib.stof_train_wgrad_batch_workspace_bytes(cnt, 7)
+                ws = getattr(self, '_wgrad_batch_ws', None)
+                if ws is None or ws.numel() < need:
+                    ws = self._wgrad_batch_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+                arr = lambda ts: (ctypes.c_void_p * cnt)(*[_lib.ptr(t) for t in ts])
+                _lib.check(lib.stof_train_wgrad_batch(arr([a for a, _, _ in pairs]), arr([d for _, d, _ in pairs]),
+                                                      arr([self.g[nm + '.weight'] for _, _, nm in pairs]),
+                                                      arr([self.g[nm + '.bias'] for _, _, nm in pairs]), cnt, n, L, 7,
+                                                      1.0 / self._gscale, _lib.ptr(ws), ws.numel(), st), 'stof_train_wgrad_batch')
+            else:
+                for a, d, nm in pairs:
+                    self._wgrad(a, d, nm, 64, 64, 7)
             gg = T[11]                                                                   # dL/dx_0 without the long skip
         else:
             gg = self._conv(g6, bwd['conv12'], None, 64, 64, 7)                       # d/dx5
@@ -350,8 +371,21 @@ class StofNetFunction(torch.autograd.Function):
                 # dloss/dpred of a mean-reduced loss is ~1e-6: fp16-subnormal for the split-fp16 data-gradient
                 # convolutions.  Scale by the power of two that brings the largest entry to [1, 2) (exact); the
                 # weight-gradient kernels multiply by 1/scale (exact).  One host read per step.
-                amax = float(dpred.abs().amax())
+                # The same read carries the range-guard word of the PREVIOUS backward (below).
+                prev = getattr(engine, '_bwd_overflow', None)
+                word = dpred.abs().amax().reshape(1)
+                if prev is not None:
+                    word = torch.cat([word, prev])
+                    engine._bwd_overflow = None
+                host = word.tolist()
+                amax = host[0]
+                if prev is not None and host[1] != 0.0:
+                    ctx.saved = None
+                    raise FloatingPointError("StofNet(train_precision='f16x3'): the previous backward produced a non-finite gradient "
+                                             "(a back-propagated value left the fp16 range; its gradients were zeroed); train with "
+                                             "train_precision='fp32'")
                 if not math.isfinite(amax):
+                    ctx.saved = None
                     raise FloatingPointError("StofNet(train_precision='f16x3'): non-finite dloss/dpred (an activation left the fp16 "
                                              "range of the split-fp16 arithmetic?); train with train_precision='fp32'")
                 if amax > 0.0 and math.isfinite(amax):
@@ -367,10 +401,15 @@ class StofNetFunction(torch.autograd.Function):
             if ctx.needs_input_grad[0]:                 # d loss / d frame: the reference's autograd yields it (models/stofnet.py:45)
                 dx = torch.empty((n, saved['L']), dtype=torch.float32, device=engine.dev)
             engine._backward_saved(saved, dpred, g, gscale, dx)
-            if engine.prec == 1 and not bool(torch.isfinite(flat).all()):      # range guard of the split-fp16 backward (one more host read)
-                ctx.saved = None
-                raise FloatingPointError("StofNet(train_precision='f16x3'): a back-propagated value left the fp16 range (non-finite "
-                                         "gradient); train with train_precision='fp32'")
+            if engine.prec == 1:
+                # Range guard of the split-fp16 backward, without a second host read: a non-finite gradient zeroes this step's
+                # gradients on the device (the optimizer step moves nothing but weight decay) and sets a device word that the NEXT
+                # backward reads together with its amax (or StofNet.raise_if_overflow() at any time) -> FloatingPointError.
+                bad = ~torch.isfinite(flat).all()
+                flat.masked_fill_(bad, 0.0)
+                if dx is not None:
+                    dx.masked_fill_(bad, 0.0)
+                engine._bwd_overflow = bad.float().reshape(1)
         ctx.saved = None
         return (None if dx is None else dx.view(n, 1, saved['L']), None, None) + tuple(g[name] for name in ctx.names)
 

@@ -1,6 +1,6 @@
 """GPU time (events) and wall time per toa_detect call for the alternative launch sequences, per batch size:
 explicit threshold: fused one-launch kernel vs envelope kernel + row kernel; default threshold: stof_toa_moments vs
-envelope kernel + stof_gradpeak_moments.  -> gpurun_out/r03_gradpeak_paths.json"""
+envelope kernel + stof_gradpeak_moments.  -> gpurun_out/r04_gradpeak_paths.json"""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
@@ -32,4 +32,4 @@ for rows in (256, 1024, 2048, 4096, 8192, 32768):
             print(json.dumps(rec), flush=True)
             out.append(rec)
 os.makedirs('gpurun_out', exist_ok=True)
-json.dump(out, open('gpurun_out/r03_gradpeak_paths.json', 'w'), indent=1)
+json.dump(out, open('gpurun_out/r04_gradpeak_paths.json', 'w'), indent=1)
