@@ -335,25 +335,28 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
             }
         }
         // backward, masked layers: saved activation of the lane's 8 channels of its row of N-tile n (the forward dump's tensor
-        // 1 + 2 k, k = 5 - j/2), requested one tile before the epilogue that uses it
+        // 1 + 2 k, k = 5 - j/2), requested a whole pass (~2 us) before the epilogue that uses it: behind pass-A tile n for pass-B tile n
+        // (r4: requested one tile ahead, ~0.4 us, every epilogue waited out the rest of the HBM round trip -- SQ_WAIT_ANY 0.42)
         const float* const ysp = (BWD && KIND == 3) ? p.fwd_dump + (size_t)(1 + 2 * (5 - (j >> 1))) * p.dump_stride + 32 * mi + 8 * q4 : nullptr;
-        float4 ysv[2][2];
+        float4 ysv[KIND == 3 ? NN : 1][2];
         auto ys_load = [&](int n) {
             if constexpr (KIND == 3) {
-                ysv[n & 1][0] = ysv[n & 1][1] = make_float4(1.f, 1.f, 1.f, 1.f);
+                // ONE unconditional load per tile: rows that are not valid (gap rows, stream ends) read row 0 of the tensor -- their
+                // results are overwritten by the padding fix-up below.  (A conditional load with a constant default made the compiler
+                // fold the `> 0` compares into the load's block, behind an s_waitcnt vmcnt(0): every request waited out its own HBM
+                // round trip, 55 k of the backward step's 200 k cycles.)
+                size_t row;
                 if (span_ok) {
-                    const float* const s0 = ysp + ((size_t)nww * Ltrue + tww + i16 + 16 * n) * NF;
-                    ysv[n & 1][0] = ld4(s0);
-                    ysv[n & 1][1] = ld4(s0 + 4);
+                    row = (size_t)nww * Ltrue + tww + i16 + 16 * n;
                 } else {
                     bool valid;
                     int slot, nw, tw, tk;
                     row_of(n, valid, slot, nw, tw, tk);
-                    if (valid) {
-                        ysv[n & 1][0] = ld4(ysp + ((size_t)nw * Ltrue + tw) * NF);
-                        ysv[n & 1][1] = ld4(ysp + ((size_t)nw * Ltrue + tw) * NF + 4);
-                    }
+                    row = valid ? (size_t)nw * Ltrue + tw : 0;
                 }
+                const float* const s0 = ysp + row * NF;
+                ysv[n][0] = ld4(s0);
+                ysv[n][1] = ld4(s0 + 4);
             }
         };
 
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                     else { e.v[x] = __builtin_amdgcn_fmed3f(e.v[x], e.w[x], 3.0e38f); STOF_PIN(e.v[x]); }
                 } else if constexpr (KIND == 3) {                // times lrelu'(saved activation): one value per slot
                     if (k < 8) {
-                        const float4 sv = ysv[t & 1][k >> 2];
+                        const float4 sv = ysv[KIND == 3 ? t : 0][k >> 2];
                         const float sx = (k & 3) == 0 ? sv.x : (k & 3) == 1 ? sv.y : (k & 3) == 2 ? sv.z : sv.w;
                         e.v[k] = sx > 0.f ? e.v[k] : 0.01f * e.v[k];
                         STOF_PIN(e.v[k]);
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                                 const int cw = li / FRAGS_PER_CHUNK, f = li % FRAGS_PER_CHUNK;
                                 W[ps ^ 1][cw][f] = wload((ps == 0 ? cthis + HC : cnext) + cw, f);
                             }
-                            if (BWD && KIND == 3 && ps == 1 && c == HC - 1) ys_load(n);
+                            if (BWD && KIND == 3 && ps == 0 && c == HC - 1) ys_load(n);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }

@@ -2022,6 +2022,20 @@ int train_sweep_geometry(const stof_net_desc* desc, BodyParams& bp, int64_t N, i
 }
 }  // namespace
 
+#ifdef STOF_STAMPS
+// diagnostic builds only: cycle stamps of the training sweeps (slot 0 = forward, 1 = backward), read back by stof_debug_train_stamps
+static unsigned long long* train_stamp_last[2] = {nullptr, nullptr};
+static unsigned long long* train_stamp_buf(int which) {
+    static unsigned long long* buf[2] = {nullptr, nullptr};
+    if (!buf[which] && hipMalloc(&buf[which], 256 * 4 * 8 * 8) != hipSuccess) return nullptr;
+    (void)hipMemset(buf[which], 0, 256 * 4 * 8 * 8);
+    return train_stamp_last[which] = buf[which];
+}
+extern "C" int stof_debug_train_stamps(int which, unsigned long long* host_out) {
+    if (which < 0 || which > 1 || !train_stamp_last[which]) return STOF_ERR_BAD_ARG;
+    return hipMemcpy(host_out, train_stamp_last[which], 256 * 4 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+#endif
 extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev, const float* x, const float* sgb_expand,
                                 float* dump, float* y, int64_t N, int64_t L, void* stream_) {
     if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
@@ -2053,6 +2067,9 @@ extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev,
     bp.onset_ws = nullptr; bp.onset_slots = 0; bp.onset_seg_slots = 0;
     bp.dump = dump; bp.dump_stride = (long long)N * L * NF;
     bp.gin = nullptr; bp.fwd_dump = nullptr;
+#ifdef STOF_STAMPS
+    bp.stamps = train_stamp_buf(0);
+#endif
     int64_t wgs = 0;
     if (int st = train_sweep_geometry(desc, bp, N, L, &wgs)) return st;
     hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), lds_bytes, stream, bp);
@@ -2180,6 +2197,9 @@ extern "C" int stof_train_sweep_bwd(const stof_net_desc* desc, const void* blob_
     bp.onset_ws = nullptr; bp.onset_slots = 0; bp.onset_seg_slots = 0;
     bp.dump = dump; bp.dump_stride = (long long)N * L * NF;
     bp.gin = g6; bp.fwd_dump = fwd_dump;
+#ifdef STOF_STAMPS
+    bp.stamps = train_stamp_buf(1);
+#endif
     int64_t wgs = 0;
     if (int st = train_sweep_geometry(desc, bp, N, L, &wgs)) return st;
     hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), lds_bytes, stream, bp);
