@@ -75,13 +75,30 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
     for (int i = tid; i < BODY_P2_C1F; i += 256) c1l[i] = p.c1[i];
     const int cq = tid & 15, rl = tid >> 4;
     __syncthreads();
+    // (waveforms of at least 2 S rows wrap at most once per offset: selects instead of loops -- the general loops compiled to
+    // ~40 scalar instructions with a division per layer set-up)
+    const bool long_wf = Lp >= 2 * S;
     auto decode_row = [&](int nB, int tB, int off, int& n, int& t) {
         n = nB;
         t = tB + off;
-        if (Lp >= 2 * S) {
-            if (t >= Lp) { t -= Lp; n += 1; }
+        if (long_wf) {
+            const bool wrap = t >= Lp;
+            t -= wrap ? Lp : 0;
+            n += wrap ? 1 : 0;
         } else {
             while (t >= Lp) { t -= Lp; n += 1; }
+        }
+    };
+    // row tB - back (0 <= back <= 36) of waveform nB
+    auto step_back = [&](int nB, int tB, int back, int& n, int& t) {
+        n = nB;
+        t = tB - back;
+        if (long_wf) {
+            const bool wrap = t < 0;
+            t += wrap ? Lp : 0;
+            n -= wrap ? 1 : 0;
+        } else {
+            while (t < 0) { t += Lp; n -= 1; }
         }
     };
 
@@ -123,17 +140,28 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                 sgA = ld4(sgl + (wid & 7) * NF + 4 * cq);
                 sgB = ld4(sgl + ((wid + 1) & 7) * NF + 4 * cq);
             }
+            // two channels per v_pk_fma_f32 (the sample is the broadcast operand): half the FMA instructions of the pass, the same
+            // fused multiply-adds in the same order per channel
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            f2v wq[2][9], bq2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int d = 0; d < 9; ++d) wq[h][d] = f2v{w1[2 * h][d], w1[2 * h + 1][d]};
+                bq2[h] = f2v{b1[2 * h], b1[2 * h + 1]};
+            }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const bool first = it < sw;
                 const float sg[4] = {first ? sgA.x : sgB.x, first ? sgA.y : sgB.y, first ? sgA.z : sgB.z, first ? sgA.w : sgB.w};
                 float v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float a = b1[i];
+                for (int h = 0; h < 2; ++h) {
+                    f2v a = bq2[h];
 #pragma unroll
-                    for (int d = 0; d < 9; ++d) a = fmaf(w1[i][d], xs[it + d], a);
-                    v[i] = fmaxf(a, 0.f) + sg[i];
+                    for (int d = 0; d < 9; ++d) a = __builtin_elementwise_fma(wq[h][d], f2v{xs[it + d], xs[it + d]}, a);
+                    v[2 * h] = fmaxf(a[0], 0.f) + sg[2 * h];
+                    v[2 * h + 1] = fmaxf(a[1], 0.f) + sg[2 * h + 1];
                 }
                 char* const row = dst + ((g0 + it) & (RING - 1)) * ROWB;
                 if (dump0 != nullptr)
@@ -296,8 +324,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
     auto layer = [&](auto kind_c, const int j) {
         constexpr int KIND = decltype(kind_c)::value;
         constexpr bool INPL = KIND == 0;
-        int nR = nS, tR = tS - 3 * j;             // waveform / time of the layer's first row R0 = F - S - lag (may precede the stream)
-        while (tR < 0) { tR += Lp; nR -= 1; }
+        int nR, tR;                               // waveform / time of the layer's first row R0 = F - S - lag (may precede the stream)
+        step_back(nS, tS, 3 * j, nR, tR);
         const char* const src = (j & 1) ? Xr : Yr;             // odd sweep layers read ring X and write ring Y
         char* const dst = (j & 1) ? Yr : Xr;
         const int R0 = F - S - 3 * j;
@@ -547,8 +575,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
 
     // conv_last with r <= 16: one 16-channel output tile on v_mfma_f32_16x16x32_f16, every wave 48 rows of the step (as r3)
     auto conv_last16 = [&]() {
-        int nR = nS, tR = tS - LAG_LAST;
-        while (tR < 0) { tR += Lp; nR -= 1; }
+        int nR, tR;
+        step_back(nS, tS, LAG_LAST, nR, tR);
         const char* const src = Yr;               // sweep layer 12 reads conv12's output
         const int R0 = F - S - LAG_LAST;
         const int j16 = lane & 15;
@@ -639,8 +667,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
     // conv_last with r > 16 (64-wide output block, of which r channels are real): tile-major on the wave's six N-tiles, its
     // 6 chunks in weight buffer 1 (free: conv12's pass B is over; buffer 0 already holds the next step's first half-layer)
     auto conv_last_wide = [&]() {
-        int nR = nS, tR = tS - LAG_LAST;
-        while (tR < 0) { tR += Lp; nR -= 1; }
+        int nR, tR;
+        step_back(nS, tS, LAG_LAST, nR, tR);
         const char* const src = Yr;
         const int R0 = F - S - LAG_LAST;
 #pragma unroll
@@ -735,8 +763,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                 layer(std::integral_constant<int, 0>{}, 2 * pp + 2);
             }
             {
-                int nR = nS, tR = tS - 33;
-                while (tR < 0) { tR += Lp; nR -= 1; }
+                int nR, tR;
+                step_back(nS, tS, 33, nR, tR);
                 x0_pass(Yr, F - S - 33, nR, tR, false);
                 STAMP_ADD(1);
                 __syncthreads();
