@@ -300,6 +300,12 @@ size_t stof_train_wgrad_batch_workspace_bytes(int32_t count, int32_t K);
 int stof_train_wgrad_batch(const float* const* x, const float* const* dy, float* const* dw, float* const* db, int32_t count,
                            int64_t N, int64_t L, int32_t K, float out_scale, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* The same with operands stored as SPLIT ROWS (bit i of x_split / dy_split: operand i): a [N][L] tensor of 256-byte rows
+ * [64 x fp16 hi | 64 x fp16 lo] with value = hi + lo -- what stof_train_sweep_split / stof_train_sweep_bwd_split dump (the halves the
+ * sweeps compute anyway), so this kernel stages them into LDS without converting.  Split operands must be 16-byte aligned.  */
+int stof_train_wgrad_batch_split(const float* const* x, const float* const* dy, float* const* dw, float* const* db, int32_t count,
+                                 uint32_t x_split, uint32_t dy_split, int64_t N, int64_t L, int32_t K, float out_scale,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 /* conv1 (1->64, k9) + ReLU forward to channel-last, and its weight gradient (g masked by relu').    */
 int stof_train_conv1(const float* x, const float* w, const float* b, float* y, int64_t N, int64_t L, void* stream);
 size_t stof_train_conv1_wgrad_workspace_bytes(void);
@@ -370,6 +376,10 @@ int stof_train_sweep_pack(const stof_net_desc* desc, const float* const* params_
 size_t stof_train_sweep_dump_floats(int64_t N, int64_t L);
 int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev, const float* x, const float* sgb_expand, float* dump,
                      float* y, int64_t N, int64_t L, void* stream);
+/* stof_train_sweep with dump tensors 0..10 written as SPLIT ROWS (see stof_train_wgrad_batch_split); tensor 11 (conv12's output,
+ * read by conv_last's weight gradient) stays fp32.  STOF_ERR_UNSUPPORTED when the two-pass sweep kernel is switched off.  */
+int stof_train_sweep_split(const stof_net_desc* desc, const void* blob_dev, const float* x, const float* sgb_expand, float* dump,
+                           float* y, int64_t N, int64_t L, void* stream);
 /* The data-gradient chain of the same step as ONE backward sweep (the mirror image of stof_train_sweep): from
  * g6[N][L][64] = dL/d(conv12 output) (= stof_train_conv of conv_last's transposed weights on dL/dpred) it runs conv12^T,
  * conv11^T .. conv2^T with the leaky-ReLU derivatives (read off the sign of the saved activations in fwd_dump = the dump
@@ -395,6 +405,12 @@ int stof_train_loss_target(const int64_t* gt_idx, int64_t G, const float* taps7,
                            float* target, float* tmax, void* stream);
 int stof_train_loss_grad(const float* pred, float* target, const float* tmax, int64_t N, int64_t M, float amplitude,
                          float lambda, float grad_scale, float* dpred, double* loss, void* stream);
+/* stof_train_sweep_bwd on a forward dump written by stof_train_sweep_split (the leaky-ReLU derivative is read off the sign of the
+ * saved activation's hi half: an activation with |y| < 2^-25 counts as not positive), all eleven output tensors as split rows. */
+int stof_train_sweep_bwd_split(const stof_net_desc* desc, const void* blob_dev, const float* g6, const float* fwd_dump,
+                               float* dump, int64_t N, int64_t L, void* stream);
+/* out[rows][64] = (hi + lo of the split rows a_split) + b  (the long-skip join on the backward sweep's split-row dL/dx_0).  */
+int stof_train_add_split(const float* a_split, const float* b, float* out, int64_t rows, void* stream);
 /* out = a + b (gradient joins of the residual / long-skip branches, models/stofnet.py:56,62).         */
 int stof_train_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* torch.optim.AdamW step on one flat parameter vector (main.py:179,248).                             */

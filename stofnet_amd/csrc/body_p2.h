@@ -33,7 +33,10 @@ __device__ __forceinline__ void lds_stq(unsigned a, uint4 v) {
     *(lds_u4_t*)(a) = w;
 }
 
-template <int S, int RING, int RAWRING, bool DUMP = false, bool BWD = false>
+// HL (training sweeps, r4): the dumps are written as SPLIT ROWS -- [64 x fp16 hi | 64 x fp16 lo], the 256 bytes of an fp32 row, in
+// the layout the rings and the weight-gradient kernel's LDS tiles use (the epilogue has both halves anyway) -- except the forward
+// sweep's tensor 11 (conv12's output, read by fp32 kernels); the backward sweep then reads the saved activations' hi halves.
+template <int S, int RING, int RAWRING, bool DUMP = false, bool BWD = false, bool HL = false>
 __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams p) {
     constexpr int PREC = STOF_PREC_F16X3;
     constexpr int NCHUNK_STEP = 11 * BODY_CHUNKS_K7;          // k7 weight chunks of a sweep step (conv_last's follow them in the blob)
@@ -164,12 +167,17 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                     v[2 * h + 1] = fmaxf(a[1], 0.f) + sg[2 * h + 1];
                 }
                 char* const row = dst + ((g0 + it) & (RING - 1)) * ROWB;
-                if (dump0 != nullptr)
+                if (!HL && dump0 != nullptr)
                     st4(dump0 + ((size_t)(n0 + nR) * Ltrue + tR + rl * NIT + it) * NF + 4 * cq, make_float4(v[0], v[1], v[2], v[3]));
                 const half2v h01 = cvt_h2(v[0], v[1]), h23 = cvt_h2(v[2], v[3]);
                 half2v l01, l23;                    // v - hi is exact in fp32: one rounding to fp16 (v_fma_mixlo_f16 / mixhi)
                 l01[0] = (_Float16)mix_sub(h01[0], v[0], one_x0); l01[1] = (_Float16)mix_sub(h01[1], v[1], one_x0);
                 l23[0] = (_Float16)mix_sub(h23[0], v[2], one_x0); l23[1] = (_Float16)mix_sub(h23[1], v[3], one_x0);
+                if (HL && dump0 != nullptr) {
+                    char* const drow = reinterpret_cast<char*>(dump0 + ((size_t)(n0 + nR) * Ltrue + tR + rl * NIT + it) * NF);
+                    *reinterpret_cast<uint2*>(drow + 8 * cq) = make_uint2(h2_bits(h01), h2_bits(h23));
+                    *reinterpret_cast<uint2*>(drow + 128 + 8 * cq) = make_uint2(h2_bits(l01), h2_bits(l23));
+                }
                 *reinterpret_cast<uint2*>(row + 8 * cq) = make_uint2(h2_bits(h01), h2_bits(h23));
                 *reinterpret_cast<uint2*>(row + 128 + 8 * cq) = make_uint2(h2_bits(l01), h2_bits(l23));
             }
@@ -207,9 +215,15 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
             }
             const float4 o = ok ? make_float4(v[0] + sg.x, v[1] + sg.y, v[2] + sg.z, v[3] + sg.w)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (dump0 != nullptr && ok && t >= p.halo && t < p.halo + p.seg_len)
+            if (!HL && dump0 != nullptr && ok && t >= p.halo && t < p.halo + p.seg_len)
                 st4(dump0 + ((size_t)nw * Ltrue + tw) * NF + 4 * cq, o);
-            store_act4<PREC>(dst + ((g0 + it) & (RING - 1)) * ROWB, 4 * cq, o);
+            char* const lrow = dst + ((g0 + it) & (RING - 1)) * ROWB;
+            store_act4<PREC>(lrow, 4 * cq, o);
+            if (HL && dump0 != nullptr && ok && t >= p.halo && t < p.halo + p.seg_len) {      // the split image just written (same thread)
+                char* const drow = reinterpret_cast<char*>(dump0 + ((size_t)nw * Ltrue + tw) * NF);
+                *reinterpret_cast<uint2*>(drow + 8 * cq) = *reinterpret_cast<const uint2*>(lrow + 8 * cq);
+                *reinterpret_cast<uint2*>(drow + 128 + 8 * cq) = *reinterpret_cast<const uint2*>(lrow + 128 + 8 * cq);
+            }
         }
     };
 
@@ -321,8 +335,9 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
     // E = the next instruction of the previous tile's epilogue queue (pass B; 42 slots per tile for its <= 41 instructions),
     // A = the three instructions of the LDS address of the unit PD + 1 ahead when its tap changes, G = one weight-fragment load
     // for the other half-layer buffer (28 per pass).
-    auto layer = [&](auto kind_c, const int j) {
+    auto layer = [&](auto kind_c, const int j, auto hl_c) {
         constexpr int KIND = decltype(kind_c)::value;
+        constexpr bool LHL = decltype(hl_c)::value;   // this layer's dump as split rows
         constexpr bool INPL = KIND == 0;
         int nR, tR;                               // waveform / time of the layer's first row R0 = F - S - lag (may precede the stream)
         step_back(nS, tS, 3 * j, nR, tR);
@@ -352,21 +367,29 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
         const bool span_ok = (gw0 >= 0) && (gw0 + 16 * NN - 1 < gend) && (tkw + 16 * NN - 1 < L) && (tww >= 0) &&
                              (tww + 16 * NN - 1 < Ltrue) && (tkw >= p.halo) && (tkw + 16 * NN - 1 < p.halo + p.seg_len);
         float* const dumpj = DUMP ? p.dump + (size_t)j * p.dump_stride : nullptr;
-        float* dlane = nullptr;
+        // the lane's two 16-byte stores of its row of tile t: fp32 rows -> channels 8 q4 .. + 3 | + 4 .. + 7 (bytes + 0, + 16);
+        // split rows -> hi | lo of the 8 channels (bytes + 0, + 128).  Spans with padding rows store into a scrap area behind the
+        // twelve tensors (32 bytes per lane) and the fix-up below writes the valid rows from the LDS image.
+        char* dlane = nullptr;
         long long dstep = 0;
+        int dsecond = 16;
         if constexpr (DUMP) {
             if (span_ok) {
-                dlane = dumpj + ((size_t)nww * Ltrue + tww + i16) * NF + 32 * mi + 8 * q4;
-                dstep = 16 * NF;
+                dlane = reinterpret_cast<char*>(dumpj + ((size_t)nww * Ltrue + tww + i16) * NF) + (32 * mi + 8 * q4) * (LHL ? 2 : 4);
+                dstep = 16 * NF * 4;
+                dsecond = LHL ? 128 : 16;
             } else {
-                dlane = p.dump + 12 * p.dump_stride + 8 * lane;
+                dlane = reinterpret_cast<char*>(p.dump + 12 * p.dump_stride + 8 * lane);
             }
         }
         // backward, masked layers: saved activation of the lane's 8 channels of its row of N-tile n (the forward dump's tensor
         // 1 + 2 k, k = 5 - j/2), requested a whole pass (~2 us) before the epilogue that uses it: behind pass-A tile n for pass-B tile n
         // (r4: requested one tile ahead, ~0.4 us, every epilogue waited out the rest of the HBM round trip -- SQ_WAIT_ANY 0.42)
-        const float* const ysp = (BWD && KIND == 3) ? p.fwd_dump + (size_t)(1 + 2 * (5 - (j >> 1))) * p.dump_stride + 32 * mi + 8 * q4 : nullptr;
-        float4 ysv[KIND == 3 ? NN : 1][2];
+        // HL: the forward dump holds split rows; the mask needs the sign of the value = the sign of its hi half (16 bytes per lane and
+        // tile instead of 32).  An activation with |y| < 2^-25 has hi = +-0 and reads as 'not positive' (slope 0.01) whatever its sign --
+        // the forward arithmetic saw such a value as hi + lo ~ 0 too.
+        const float* const ysp = (BWD && KIND == 3) ? p.fwd_dump + (size_t)(1 + 2 * (5 - (j >> 1))) * p.dump_stride + (HL ? 16 * mi + 4 * q4 : 32 * mi + 8 * q4) : nullptr;
+        float4 ysv[KIND == 3 ? NN : 1][HL ? 1 : 2];
         auto ys_load = [&](int n) {
             if constexpr (KIND == 3) {
                 // ONE unconditional load per tile: rows that are not valid (gap rows, stream ends) read row 0 of the tensor -- their
@@ -384,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                 }
                 const float* const s0 = ysp + row * NF;
                 ysv[n][0] = ld4(s0);
-                ysv[n][1] = ld4(s0 + 4);
+                if constexpr (!HL) ysv[n][1] = ld4(s0 + 4);
             }
         };
 
@@ -438,9 +461,16 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                     else { e.v[x] = __builtin_amdgcn_fmed3f(e.v[x], e.w[x], 3.0e38f); STOF_PIN(e.v[x]); }
                 } else if constexpr (KIND == 3) {                // times lrelu'(saved activation): one value per slot
                     if (k < 8) {
-                        const float4 sv = ysv[KIND == 3 ? t : 0][k >> 2];
-                        const float sx = (k & 3) == 0 ? sv.x : (k & 3) == 1 ? sv.y : (k & 3) == 2 ? sv.z : sv.w;
-                        e.v[k] = sx > 0.f ? e.v[k] : 0.01f * e.v[k];
+                        if constexpr (HL) {
+                            const float4 sv = ysv[KIND == 3 ? t : 0][0];      // 8 fp16 hi halves: value k = half k & 1 of word k >> 1
+                            const float wf = (k >> 1) == 0 ? sv.x : (k >> 1) == 1 ? sv.y : (k >> 1) == 2 ? sv.z : sv.w;
+                            const half2v hv = bits_h2(__float_as_uint(wf));
+                            e.v[k] = hv[k & 1] > (_Float16)0.f ? e.v[k] : 0.01f * e.v[k];
+                        } else {
+                            const float4 sv = ysv[KIND == 3 ? t : 0][k >> 2];
+                            const float sx = (k & 3) == 0 ? sv.x : (k & 3) == 1 ? sv.y : (k & 3) == 2 ? sv.z : sv.w;
+                            e.v[k] = sx > 0.f ? e.v[k] : 0.01f * e.v[k];
+                        }
                         STOF_PIN(e.v[k]);
                     }
                 }
@@ -462,8 +492,13 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                 lds_stq(sl + 128, make_uint4(e.l[0], e.l[1], e.l[2], e.l[3]));
             } else if (q == 41) {
                 if constexpr (DUMP) {
-                    st4(dlane + t * dstep, make_float4(e.v[0], e.v[1], e.v[2], e.v[3]));
-                    st4(dlane + t * dstep + 4, make_float4(e.v[4], e.v[5], e.v[6], e.v[7]));
+                    if constexpr (LHL) {
+                        *reinterpret_cast<uint4*>(dlane + t * dstep) = make_uint4(e.h[0], e.h[1], e.h[2], e.h[3]);
+                        *reinterpret_cast<uint4*>(dlane + t * dstep + dsecond) = make_uint4(e.l[0], e.l[1], e.l[2], e.l[3]);
+                    } else {
+                        st4(reinterpret_cast<float*>(dlane + t * dstep), make_float4(e.v[0], e.v[1], e.v[2], e.v[3]));
+                        st4(reinterpret_cast<float*>(dlane + t * dstep + dsecond), make_float4(e.v[4], e.v[5], e.v[6], e.v[7]));
+                    }
                 }
             }
         };
@@ -558,6 +593,12 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                     *reinterpret_cast<uint4*>(dst + slot) = make_uint4(0u, 0u, 0u, 0u);
                     *reinterpret_cast<uint4*>(dst + slot + 128) = make_uint4(0u, 0u, 0u, 0u);
                 } else if (DUMP && tk >= p.halo && tk < p.halo + p.seg_len) {
+                    if constexpr (LHL) {
+                        char* const o = reinterpret_cast<char*>(dumpj + ((size_t)nw * Ltrue + tw) * NF) + (32 * mi + 8 * q4) * 2;
+                        *reinterpret_cast<uint4*>(o) = ldq(dst + slot);
+                        *reinterpret_cast<uint4*>(o + 128) = ldq(dst + slot + 128);
+                        continue;
+                    }
                     const half8 hh8 = as_h8(ldq(dst + slot)), ll8 = as_h8(ldq(dst + slot + 128));
                     float* const o = dumpj + ((size_t)nw * Ltrue + tw) * NF + 32 * mi + 8 * q4;
                     st4(o, make_float4((float)hh8[0] + (float)ll8[0], (float)hh8[1] + (float)ll8[1],
@@ -759,8 +800,8 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
             // conv2 .. conv11: (leaky ReLU, residual add) x 5; then the long skip seeds ring Y with x0 and conv12 adds in place
 #pragma unroll 1
             for (int pp = 0; pp < 5; ++pp) {
-                layer(std::integral_constant<int, 1>{}, 2 * pp + 1);
-                layer(std::integral_constant<int, 0>{}, 2 * pp + 2);
+                layer(std::integral_constant<int, 1>{}, 2 * pp + 1, std::bool_constant<HL>{});
+                layer(std::integral_constant<int, 0>{}, 2 * pp + 2, std::bool_constant<HL>{});
             }
             {
                 int nR, tR;
@@ -775,7 +816,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
                 // the layer's 56 weight fragments out of the step loop (112 registers), spills them and reloads each behind vmcnt(0)
                 int j12;
                 asm volatile("s_mov_b32 %0, 11" : "=s"(j12));
-                layer(std::integral_constant<int, 0>{}, j12);
+                layer(std::integral_constant<int, 0>{}, j12, std::false_type{});      // conv12's output stays fp32 (conv_last's weight gradient reads it)
             }
             if (p.last16 != nullptr) conv_last16();
             else conv_last_wide();
@@ -784,12 +825,12 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
             {
                 int j1;                             // opaque for the same reason as conv12's layer number in the forward sweep
                 asm volatile("s_mov_b32 %0, 1" : "=s"(j1));
-                layer(std::integral_constant<int, 2>{}, j1);
+                layer(std::integral_constant<int, 2>{}, j1, std::bool_constant<HL>{});
             }
 #pragma unroll 1
             for (int pp = 0; pp < 5; ++pp) {
-                layer(std::integral_constant<int, 3>{}, 2 * pp + 2);
-                layer(std::integral_constant<int, 0>{}, 2 * pp + 3);
+                layer(std::integral_constant<int, 3>{}, 2 * pp + 2, std::bool_constant<HL>{});
+                layer(std::integral_constant<int, 0>{}, 2 * pp + 3, std::bool_constant<HL>{});
             }
         }
     }

@@ -2036,8 +2036,8 @@ extern "C" int stof_debug_train_stamps(int which, unsigned long long* host_out) 
     return hipMemcpy(host_out, train_stamp_last[which], 256 * 4 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 #endif
-extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev, const float* x, const float* sgb_expand,
-                                float* dump, float* y, int64_t N, int64_t L, void* stream_) {
+static int train_sweep_impl(const stof_net_desc* desc, const void* blob_dev, const float* x, const float* sgb_expand,
+                            float* dump, float* y, int64_t N, int64_t L, void* stream_, bool split) {
     if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     const int r = desc->upsample_factor;
     if (r < 1 || r > 64) return STOF_ERR_UNSUPPORTED;
@@ -2052,11 +2052,13 @@ extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev,
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using Lds16 = BodyLds<BODY_S, BODY_RING, BODY_RAWRING, ROWF16>;
     static const bool p2 = body_p2_enabled();
-    auto kernel = p2 ? &body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING, true, false>
-                     : &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, false>;
+    if (split && !p2) return STOF_ERR_UNSUPPORTED;              // split-row dumps exist in the two-pass kernel only
+    auto kernel = split ? &body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING, true, false, true>
+                  : p2  ? &body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING, true, false>
+                        : &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, false>;
     const size_t lds_bytes = Lds16::BYTES + (p2 ? BODY_P2_C1F * sizeof(float) : 0);
-    static LdsLimitOnce lds;
-    if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)lds_bytes)) return st;
+    static LdsLimitOnce lds[2];
+    if (int st = lds[split ? 1 : 0].ensure(reinterpret_cast<const void*>(kernel), (int)lds_bytes)) return st;
     const float* base = static_cast<const float*>(blob_dev);
     BodyParams bp;
     bp.x = x; bp.sgb = has_sgb ? sgb_expand : nullptr; bp.y = y;
@@ -2074,6 +2076,15 @@ extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev,
     if (int st = train_sweep_geometry(desc, bp, N, L, &wgs)) return st;
     hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), lds_bytes, stream, bp);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_sweep(const stof_net_desc* desc, const void* blob_dev, const float* x, const float* sgb_expand,
+                                float* dump, float* y, int64_t N, int64_t L, void* stream) {
+    return train_sweep_impl(desc, blob_dev, x, sgb_expand, dump, y, N, L, stream, false);
+}
+extern "C" int stof_train_sweep_split(const stof_net_desc* desc, const void* blob_dev, const float* x, const float* sgb_expand,
+                                      float* dump, float* y, int64_t N, int64_t L, void* stream) {
+    return train_sweep_impl(desc, blob_dev, x, sgb_expand, dump, y, N, L, stream, true);
 }
 
 // ---- training forward of the SemiGlobalBlock's contracting path: relu(conv1) -> contract conv -> lrelu -> max-pool(80) fused as in
@@ -2174,8 +2185,8 @@ extern "C" int stof_train_sweep_bwd_pack(const float* const* conv_weights_dev, v
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
-extern "C" int stof_train_sweep_bwd(const stof_net_desc* desc, const void* blob_dev, const float* g6, const float* fwd_dump,
-                                    float* dump, int64_t N, int64_t L, void* stream_) {
+static int train_sweep_bwd_impl(const stof_net_desc* desc, const void* blob_dev, const float* g6, const float* fwd_dump,
+                                float* dump, int64_t N, int64_t L, void* stream_, bool split) {
     if (!desc || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     if (N == 0 || L == 0) return STOF_OK;
     if (!blob_dev || !g6 || !fwd_dump || !dump) return STOF_ERR_BAD_ARG;
@@ -2183,11 +2194,13 @@ extern "C" int stof_train_sweep_bwd(const stof_net_desc* desc, const void* blob_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using Lds16 = BodyLds<BODY_S, BODY_RING, BODY_RAWRING, ROWF16>;
     static const bool p2 = body_p2_enabled();
-    auto kernel = p2 ? &body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING, true, true>
-                     : &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, true>;
+    if (split && !p2) return STOF_ERR_UNSUPPORTED;
+    auto kernel = split ? &body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING, true, true, true>
+                  : p2  ? &body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING, true, true>
+                        : &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, true>;
     const size_t lds_bytes = Lds16::BYTES + (p2 ? BODY_P2_C1F * sizeof(float) : 0);
-    static LdsLimitOnce lds;
-    if (int st = lds.ensure(reinterpret_cast<const void*>(kernel), (int)lds_bytes)) return st;
+    static LdsLimitOnce lds[2];
+    if (int st = lds[split ? 1 : 0].ensure(reinterpret_cast<const void*>(kernel), (int)lds_bytes)) return st;
     const float* base = static_cast<const float*>(blob_dev);
     BodyParams bp;
     bp.x = nullptr; bp.sgb = nullptr; bp.y = nullptr;
@@ -2204,6 +2217,15 @@ extern "C" int stof_train_sweep_bwd(const stof_net_desc* desc, const void* blob_
     if (int st = train_sweep_geometry(desc, bp, N, L, &wgs)) return st;
     hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), lds_bytes, stream, bp);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_sweep_bwd(const stof_net_desc* desc, const void* blob_dev, const float* g6, const float* fwd_dump,
+                                    float* dump, int64_t N, int64_t L, void* stream) {
+    return train_sweep_bwd_impl(desc, blob_dev, g6, fwd_dump, dump, N, L, stream, false);
+}
+extern "C" int stof_train_sweep_bwd_split(const stof_net_desc* desc, const void* blob_dev, const float* g6, const float* fwd_dump,
+                                          float* dump, int64_t N, int64_t L, void* stream) {
+    return train_sweep_bwd_impl(desc, blob_dev, g6, fwd_dump, dump, N, L, stream, true);
 }
 
 extern "C" int stof_events_create(int32_t count, void** events_out) {

@@ -643,14 +643,23 @@ __device__ __forceinline__ uint2 tr_read(const char* p) {
     __builtin_memcpy(&u, &r, 8);
     return u;
 }
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half2v bits_h2w(unsigned u) { half2v h; __builtin_memcpy(&h, &u, 4); return h; }
 // (gx, G) = this work-group's index among the G persistent groups of its weight block; (o0, c0) = the block; cz = its c index
-template <int KMAX>
-__device__ __forceinline__ void conv_wgrad_f16x3_body(const WgradParams& p, const int gx, const int G, const int o0, const int c0, const int cz) {
+// xsplit / dysplit (r4, wave-uniform): the operand is stored as SPLIT ROWS [64 x fp16 hi | 64 x fp16 lo] (the training sweeps' dump
+// format, 256 bytes per row like fp32) and needs 64 channels: its rows go HBM -> registers -> LDS as they are, 16 bytes per
+// lane, with no vector-pipe work -- the fp32 form converts every value to hi + lo here (four instructions per value: a quarter of
+// the kernel's issue slots, and the kernel is power-limited).
+// FIXK: the kernel size is KMAX (the batched launch): with a run-time K every tap sat behind its own branch, i.e. in its own basic
+// block -- four LDS reads, a wait, three MFMAs, with no read of the next tap in flight.
+template <int KMAX, bool FIXK = false>
+__device__ __forceinline__ void conv_wgrad_f16x3_body(const WgradParams& p, const int gx, const int G, const int o0, const int c0, const int cz,
+                                                      const bool xsplit = false, const bool dysplit = false) {
     __shared__ __attribute__((aligned(16))) char dys[WG_ROWS_H * HSTRIDE];
     __shared__ __attribute__((aligned(16))) char xs[(WG_ROWS_H + 8) * HSTRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mi = wave & 1, ni = wave >> 1, ln = lane & 31, lh = lane >> 5;
-    const int K = p.K, pad = K >> 1;
+    const int K = FIXK ? KMAX : p.K, pad = K >> 1;
     floatx16 acc[KMAX];
 #pragma unroll
     for (int d = 0; d < KMAX; ++d)
@@ -665,6 +674,7 @@ __device__ __forceinline__ void conv_wgrad_f16x3_body(const WgradParams& p, cons
     constexpr int NDY = WG_ROWS_H * 16 / 256, NX = ((WG_ROWS_H + 8) * 16 + 255) / 256;
     float4 rdy[NDY], rx[NX];
     float4 dbq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dbh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // split rows: sums of the thread's piece column
     auto fetch = [&](int tile) {
         const int n = tile / p.tiles_per_wf;
         const int t0 = (tile - n * p.tiles_per_wf) * WG_ROWS_H;
@@ -673,7 +683,9 @@ __device__ __forceinline__ void conv_wgrad_f16x3_body(const WgradParams& p, cons
             const int i = tid + 256 * u, r = i >> 4, qq = i & 15;
             const int t = t0 + r, o = o0 + 4 * qq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < p.L) {
+            if (dysplit) {
+                if (t < p.L) v = ld4(p.dy + ((size_t)n * p.L + t) * 64 + 4 * qq);        // piece qq of the split row: hi 0..7 | lo 8..15
+            } else if (t < p.L) {
                 const float* src = p.dy + ((size_t)n * p.L + t) * p.cout + o;
                 if (o + 3 < p.cout) v = ld4(src);
                 else {
@@ -689,7 +701,9 @@ __device__ __forceinline__ void conv_wgrad_f16x3_body(const WgradParams& p, cons
             const int i = tid + 256 * u, r = i >> 4, qq = i & 15;
             const int t = t0 - pad + r, c = c0 + 4 * qq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < p.L && r < WG_ROWS_H + K - 1) {
+            if (xsplit) {
+                if (t >= 0 && t < p.L && r < WG_ROWS_H + K - 1) v = ld4(p.x + ((size_t)n * p.L + t) * 64 + 4 * qq);
+            } else if (t >= 0 && t < p.L && r < WG_ROWS_H + K - 1) {
                 const float* src = p.x + ((size_t)n * p.L + t) * p.cin + c;
                 if (c + 3 < p.cin) v = ld4(src);
                 else {
@@ -707,20 +721,37 @@ __device__ __forceinline__ void conv_wgrad_f16x3_body(const WgradParams& p, cons
 #pragma unroll
         for (int u = 0; u < NDY; ++u) {
             const int i = tid + 256 * u, r = i >> 4, qq = i & 15;
-            uint2 hi, lo;
-            dbq.x += rdy[u].x; dbq.y += rdy[u].y; dbq.z += rdy[u].z; dbq.w += rdy[u].w;   // bias gradient: column sums
-            split4(rdy[u], hi, lo);
-            *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 8 * qq) = hi;
-            *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 128 + 8 * qq) = lo;
+            if (dysplit) {
+                // the thread's piece column qq is the same for every row: 8 channels' hi (qq < 8) or lo halves; bias gradient = their sums
+                const float4 v = rdy[u];
+                const unsigned w4[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const half2v hv = bits_h2w(w4[e]);
+                    dbh[2 * e] += (float)hv[0];
+                    dbh[2 * e + 1] += (float)hv[1];
+                }
+                *reinterpret_cast<float4*>(dys + r * HSTRIDE + 16 * qq) = v;
+            } else {
+                uint2 hi, lo;
+                dbq.x += rdy[u].x; dbq.y += rdy[u].y; dbq.z += rdy[u].z; dbq.w += rdy[u].w;   // bias gradient: column sums
+                split4(rdy[u], hi, lo);
+                *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 8 * qq) = hi;
+                *reinterpret_cast<uint2*>(dys + r * HSTRIDE + 128 + 8 * qq) = lo;
+            }
         }
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int i = tid + 256 * u, r = i >> 4, qq = i & 15;
             if (r < WG_ROWS_H + 8) {
-                uint2 hi, lo;
-                split4(rx[u], hi, lo);
-                *reinterpret_cast<uint2*>(xs + r * HSTRIDE + 8 * qq) = hi;
-                *reinterpret_cast<uint2*>(xs + r * HSTRIDE + 128 + 8 * qq) = lo;
+                if (xsplit) {
+                    *reinterpret_cast<float4*>(xs + r * HSTRIDE + 16 * qq) = rx[u];
+                } else {
+                    uint2 hi, lo;
+                    split4(rx[u], hi, lo);
+                    *reinterpret_cast<uint2*>(xs + r * HSTRIDE + 8 * qq) = hi;
+                    *reinterpret_cast<uint2*>(xs + r * HSTRIDE + 128 + 8 * qq) = lo;
+                }
             }
         }
         __syncthreads();
@@ -745,12 +776,25 @@ __device__ __forceinline__ void conv_wgrad_f16x3_body(const WgradParams& p, cons
     if (cz == 0) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(xs);
-        *reinterpret_cast<float4*>(red + (tid >> 4) * 64 + 4 * (tid & 15)) = dbq;
+        if (dysplit) {
+            // row lane tid >> 4, piece column pc: channels 8 (pc & 7) .. + 7 of part pc >> 3 -> red[row lane][part][channel]
+            const int pc = tid & 15;
+            float* const o = red + (tid >> 4) * 128 + (pc >> 3) * 64 + 8 * (pc & 7);
+            *reinterpret_cast<float4*>(o) = make_float4(dbh[0], dbh[1], dbh[2], dbh[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(dbh[4], dbh[5], dbh[6], dbh[7]);
+        } else {
+            *reinterpret_cast<float4*>(red + (tid >> 4) * 64 + 4 * (tid & 15)) = dbq;
+        }
         __syncthreads();
         if (tid < 64) {
             float s = 0.f;
+            if (dysplit) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += red[r * 64 + tid];
+                for (int r = 0; r < 16; ++r) s += red[r * 128 + tid] + red[r * 128 + 64 + tid];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += red[r * 64 + tid];
+            }
             dbs = s;
         }
     }
@@ -785,6 +829,7 @@ struct WgradBatch {
     float* part;               // [count][G][K][64][64]
     float* dbpart;             // [count][G][64]
     int N, L, K, tiles_per_wf, total_tiles, count;
+    unsigned x_split, dy_split;    // bit i: operand of layer i is stored as split rows
     float out_scale;
 };
 template <int KMAX>
@@ -796,7 +841,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_batch_kernel(const Wg
     p.dbpart = b.dbpart + (size_t)layer * G * 64;
     p.N = b.N; p.L = b.L; p.cin = 64; p.cout = 64; p.K = b.K; p.tiles_per_wf = b.tiles_per_wf; p.total_tiles = b.total_tiles;
     p.cin_pad = 64; p.cout_pad = 64;
-    conv_wgrad_f16x3_body<KMAX>(p, (int)blockIdx.x, G, 0, 0, 0);
+    conv_wgrad_f16x3_body<KMAX, true>(p, (int)blockIdx.x, G, 0, 0, 0, (b.x_split >> layer) & 1u, (b.dy_split >> layer) & 1u);
 }
 
 // dw[o][c][d] = sum_g part[g][d][o][c];  db[o] = sum_g dbpart[g][o]   (fixed summation order).
@@ -1565,6 +1610,29 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
     else if (j < n) out[j] = a[j] + b[j];
 }
 
+// thread = (row, piece p of 8): channels 8 p .. 8 p + 7 = hi piece p + lo piece p of the split row, plus b's two float4
+__global__ __launch_bounds__(256) void add_split_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ out, long long rows) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= rows * 8) return;
+    const long long r = i >> 3;
+    const int pc = (int)(i & 7);
+    const float4 hi = ld4(a + r * 64 + 4 * pc), lo = ld4(a + r * 64 + 32 + 4 * pc);
+    const unsigned hw[4] = {__float_as_uint(hi.x), __float_as_uint(hi.y), __float_as_uint(hi.z), __float_as_uint(hi.w)};
+    const unsigned lw[4] = {__float_as_uint(lo.x), __float_as_uint(lo.y), __float_as_uint(lo.z), __float_as_uint(lo.w)};
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const half2v h = bits_h2w(hw[e]), l = bits_h2w(lw[e]);
+        v[2 * e] = (float)h[0] + (float)l[0];
+        v[2 * e + 1] = (float)h[1] + (float)l[1];
+    }
+    const float4 b0 = ld4(b + r * 64 + 8 * pc), b1 = ld4(b + r * 64 + 8 * pc + 4);
+    float* const o = out + r * 64 + 8 * pc;
+    *reinterpret_cast<float4*>(o) = make_float4(v[0] + b0.x, v[1] + b0.y, v[2] + b0.z, v[3] + b0.w);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(v[4] + b1.x, v[5] + b1.y, v[6] + b1.z, v[7] + b1.w);
+}
+
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -1727,9 +1795,9 @@ extern "C" size_t stof_train_wgrad_batch_workspace_bytes(int32_t count, int32_t 
     return (size_t)count * wgrad_batch_groups(count) * ((size_t)K * 64 * 64 + 64) * sizeof(float);
 }
 
-extern "C" int stof_train_wgrad_batch(const float* const* x, const float* const* dy, float* const* dw, float* const* db, int32_t count,
-                                      int64_t N, int64_t L, int32_t K, float out_scale, void* workspace, size_t workspace_bytes,
-                                      void* stream) {
+static int wgrad_batch_impl(const float* const* x, const float* const* dy, float* const* dw, float* const* db, int32_t count,
+                            int64_t N, int64_t L, int32_t K, float out_scale, void* workspace, size_t workspace_bytes,
+                            void* stream, uint32_t x_split, uint32_t dy_split) {
     if (!x || !dy || !dw || !db || count < 1 || count > WGRAD_BATCH_MAX || N < 0 || L < 0) return STOF_ERR_BAD_ARG;
     if (K != 7 && K != 5 && K != 3) return STOF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1746,6 +1814,7 @@ extern "C" int stof_train_wgrad_batch(const float* const* x, const float* const*
     }
     if (!workspace || workspace_bytes < stof_train_wgrad_batch_workspace_bytes(count, K)) return STOF_ERR_WORKSPACE;
     b.N = (int)N; b.L = (int)L; b.K = K; b.count = count; b.out_scale = out_scale;
+    b.x_split = x_split; b.dy_split = dy_split;
     b.tiles_per_wf = (int)((L + WG_ROWS_H - 1) / WG_ROWS_H);
     const int64_t tiles = N * b.tiles_per_wf;
     if (tiles > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
@@ -1760,6 +1829,31 @@ extern "C" int stof_train_wgrad_batch(const float* const* x, const float* const*
     else hipLaunchKernelGGL(conv_wgrad_f16x3_batch_kernel<7>, grid, dim3(256), 0, s, b);
     const int total = K * 64 * 64 + 64;
     hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((total + 63) / 64, (unsigned)count), dim3(64 * WRED_SLICES), 0, s, b, G);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_wgrad_batch(const float* const* x, const float* const* dy, float* const* dw, float* const* db, int32_t count,
+                                      int64_t N, int64_t L, int32_t K, float out_scale, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    return wgrad_batch_impl(x, dy, dw, db, count, N, L, K, out_scale, workspace, workspace_bytes, stream, 0u, 0u);
+}
+extern "C" int stof_train_wgrad_batch_split(const float* const* x, const float* const* dy, float* const* dw, float* const* db,
+                                            int32_t count, uint32_t x_split, uint32_t dy_split, int64_t N, int64_t L, int32_t K,
+                                            float out_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    for (int i = 0; i < count && i < 32; ++i)
+        if ((((x_split >> i) & 1u) && x && (reinterpret_cast<size_t>(x[i]) & 15)) ||
+            (((dy_split >> i) & 1u) && dy && (reinterpret_cast<size_t>(dy[i]) & 15))) return STOF_ERR_BAD_ARG;      // 16-byte pieces
+    return wgrad_batch_impl(x, dy, dw, db, count, N, L, K, out_scale, workspace, workspace_bytes, stream, x_split, dy_split);
+}
+
+// out = (hi + lo of the split rows a) + b   (the backward sweep's dL/dx_0 is a split-row tensor; the long skip adds the fp32 g6)
+extern "C" int stof_train_add_split(const float* a_split, const float* b, float* out, int64_t rows, void* stream) {
+    if (rows < 0) return STOF_ERR_BAD_ARG;
+    if (rows == 0) return STOF_OK;
+    if (!a_split || !b || !out) return STOF_ERR_BAD_ARG;
+    if ((reinterpret_cast<size_t>(a_split) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(out)) & 15) return STOF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(add_split_kernel, dim3(blocks_for(rows * 8)), dim3(256), 0, static_cast<hipStream_t>(stream), a_split, b, out,
+                       (long long)rows);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

@@ -153,15 +153,28 @@ class TrainEngine:
             _lib.check(lib.stof_train_sweep_pack(ctypes.byref(desc), arr, _lib.ptr(self._sweep_blob), st), 'stof_train_sweep_pack')
             dump = torch.empty(lib.stof_train_sweep_dump_floats(n, L), dtype=torch.float32, device=self.dev)
             z = torch.empty((n, L * r), dtype=torch.float32, device=self.dev)
-            _lib.check(lib.stof_train_sweep(ctypes.byref(desc), _lib.ptr(self._sweep_blob), _lib.ptr(x), _lib.ptr(e), _lib.ptr(dump),
-                                            _lib.ptr(z), n, L, st), 'stof_train_sweep')
+            # r4: when the backward pass runs as one sweep + one batched weight-gradient launch, the dumps are SPLIT ROWS
+            # ([64 x fp16 hi | 64 x fp16 lo] per 256-byte row: the halves the sweeps compute anyway) and the weight-gradient
+            # kernel stages them without converting.  STOF_TRAIN_SPLIT_DUMPS=0: fp32 dumps everywhere (A/B runs).
+            split = (keep and sweep_bwd and self.prec == 1 and os.environ.get('STOF_TRAIN_WGRAD_BATCH', '1') != '0'
+                     and os.environ.get('STOF_TRAIN_SPLIT_DUMPS', '1') != '0')
+            if split:
+                code = lib.stof_train_sweep_split(ctypes.byref(desc), _lib.ptr(self._sweep_blob), _lib.ptr(x), _lib.ptr(e), _lib.ptr(dump),
+                                                  _lib.ptr(z), n, L, st)
+                if code == _lib.STOF_ERR_UNSUPPORTED:
+                    split = False
+                else:
+                    _lib.check(code, 'stof_train_sweep_split')
+            if not split:
+                _lib.check(lib.stof_train_sweep(ctypes.byref(desc), _lib.ptr(self._sweep_blob), _lib.ptr(x), _lib.ptr(e), _lib.ptr(dump),
+                                                _lib.ptr(z), n, L, st), 'stof_train_sweep')
             if not keep:
                 return z, None
             t = dump[:12 * n * L * 64].view(12, n, L, 64)
             xs = [t[0]] + [t[2 + 2 * k] for k in range(5)]
             ys = [t[1 + 2 * k] for k in range(5)]
             saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=t[11], bwd=bwd, n=n, L=L, P=P, rem=rem,
-                         _dump=dump, desc=desc, wdev=[p[f'conv{i}.weight'] for i in range(2, 13)],
+                         _dump=dump, split=split, desc=desc, wdev=[p[f'conv{i}.weight'] for i in range(2, 13)],
                          wc=p.get(sg + 'contract_conv.weight'), wl=p['conv_last.weight'], w1=p['conv1.weight'])
             return z, saved
         if self.sgb:
@@ -236,8 +249,11 @@ class TrainEngine:
             g6 = self._conv(dz, bwd['conv_last'], None, r, 64, 3)
         else:
             _lib.check(code, 'stof_train_conv_last_dgrad')
+        split = bool(saved.get('split'))          # the forward dumps are split rows: only the sweep + batched route reads them
         batch_wgrad = (self.prec == 1 and saved.get('_dump') is not None and 'conv12' not in bwd
-                       and os.environ.get('STOF_TRAIN_WGRAD_BATCH', '1') != '0')
+                       and (split or os.environ.get('STOF_TRAIN_WGRAD_BATCH', '1') != '0'))
+        if split and not batch_wgrad:
+            raise RuntimeError('split-row dumps without the backward sweep')
         if not batch_wgrad:
             self._wgrad(xs[5], g6, 'conv12', 64, 64, 7)
         if saved.get('_dump') is not None and 'conv12' not in bwd:
@@ -250,8 +266,9 @@ class TrainEngine:
             arr = (ctypes.c_void_p * 11)(*[_lib.ptr(w.contiguous()) for w in saved['wdev']])
             _lib.check(lib.stof_train_sweep_bwd_pack(arr, _lib.ptr(self._sweep_blob_bwd), st), 'stof_train_sweep_bwd_pack')
             dumpb = torch.empty(lib.stof_train_sweep_dump_floats(n, L), dtype=torch.float32, device=self.dev)
-            _lib.check(lib.stof_train_sweep_bwd(ctypes.byref(saved['desc']), _lib.ptr(self._sweep_blob_bwd), _lib.ptr(g6), _lib.ptr(saved['_dump']),
-                                                _lib.ptr(dumpb), n, L, st), 'stof_train_sweep_bwd')
+            _lib.check((lib.stof_train_sweep_bwd_split if split else lib.stof_train_sweep_bwd)(
+                ctypes.byref(saved['desc']), _lib.ptr(self._sweep_blob_bwd), _lib.ptr(g6), _lib.ptr(saved['_dump']),
+                _lib.ptr(dumpb), n, L, st), 'stof_train_sweep_bwd')
             T = dumpb[:12 * n * L * 64].view(12, n, L, 64)
             pairs = [(xs[5], g6, 'conv12')] if batch_wgrad else []                      # (input activation, output gradient, layer)
             for k in range(4, -1, -1):
@@ -267,10 +284,19 @@ class TrainEngine:
                 if ws is None or ws.numel() < need:
                     ws = self._wgrad_batch_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
                 arr = lambda ts: (ctypes.c_void_p * cnt)(*[_lib.ptr(t) for t in ts])
-                _lib.check(lib.stof_train_wgrad_batch(arr([a for a, _, _ in pairs]), arr([d for _, d, _ in pairs]),
-                                                      arr([self.g[nm + '.weight'] for _, _, nm in pairs]),
-                                                      arr([self.g[nm + '.bias'] for _, _, nm in pairs]), cnt, n, L, 7,
-                                                      1.0 / self._gscale, _lib.ptr(ws), ws.numel(), st), 'stof_train_wgrad_batch')
+                if split:
+                    # every x operand is a forward dump tensor (0..10) and every dy a backward dump tensor, except conv12's dy = g6 (fp32)
+                    all_bits = (1 << cnt) - 1
+                    _lib.check(lib.stof_train_wgrad_batch_split(arr([a for a, _, _ in pairs]), arr([d for _, d, _ in pairs]),
+                                                                arr([self.g[nm + '.weight'] for _, _, nm in pairs]),
+                                                                arr([self.g[nm + '.bias'] for _, _, nm in pairs]), cnt, all_bits,
+                                                                all_bits & ~1, n, L, 7, 1.0 / self._gscale, _lib.ptr(ws), ws.numel(), st),
+                               'stof_train_wgrad_batch_split')
+                else:
+                    _lib.check(lib.stof_train_wgrad_batch(arr([a for a, _, _ in pairs]), arr([d for _, d, _ in pairs]),
+                                                          arr([self.g[nm + '.weight'] for _, _, nm in pairs]),
+                                                          arr([self.g[nm + '.bias'] for _, _, nm in pairs]), cnt, n, L, 7,
+                                                          1.0 / self._gscale, _lib.ptr(ws), ws.numel(), st), 'stof_train_wgrad_batch')
             else:
                 for a, d, nm in pairs:
                     self._wgrad(a, d, nm, 64, 64, 7)
@@ -283,7 +309,11 @@ class TrainEngine:
                 u = self._conv(gg, bwd[nb], None, 64, 64, 7, ACT_LRELU, saved=ys[k])  # d/d(pre-activation of conv_a)
                 self._wgrad(xs[k], u, na, 64, 64, 7)
                 gg = self._conv(u, bwd[na], None, 64, 64, 7, residual=gg)             # d/dx_k
-        g_x0 = self._add(gg, g6)                                                  # long skip res1 (models/stofnet.py:62)
+        if split:                                                                 # long skip res1 (models/stofnet.py:62)
+            g_x0 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
+            _lib.check(lib.stof_train_add_split(_lib.ptr(gg), _lib.ptr(g6), _lib.ptr(g_x0), n * L, st), 'stof_train_add_split')
+        else:
+            g_x0 = self._add(gg, g6)
         if self.sgb and P:
             e, pooled, arg, c = saved['e'], saved['pooled'], saved['arg'], saved['c']
             ge = torch.empty((n, P, 64), dtype=torch.float32, device=self.dev)
