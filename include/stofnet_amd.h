@@ -409,6 +409,9 @@ int stof_train_loss_grad(const float* pred, float* target, const float* tmax, in
  * saved activation's hi half: an activation with |y| < 2^-25 counts as not positive), all eleven output tensors as split rows. */
 int stof_train_sweep_bwd_split(const stof_net_desc* desc, const void* blob_dev, const float* g6, const float* fwd_dump,
                                float* dump, int64_t N, int64_t L, void* stream);
+/* fp32 rows in[rows][64] -> split rows out (conv12's output gradient g6, so that every operand of
+ * stof_train_wgrad_batch_split is split: that case runs on the global_load_lds kernel).                                   */
+int stof_train_to_split_rows(const float* in, float* out, int64_t rows, void* stream);
 /* out[rows][64] = (hi + lo of the split rows a_split) + b  (the long-skip join on the backward sweep's split-row dL/dx_0).  */
 int stof_train_add_split(const float* a_split, const float* b, float* out, int64_t rows, void* stream);
 /* out = a + b (gradient joins of the residual / long-skip branches, models/stofnet.py:56,62).         */

@@ -1011,6 +1011,166 @@ __global__ __launch_bounds__(512, 4) void sgb_contract_wgrad_kernel(const SgbWgr
     if (lane < SGBW_OWN) p.dbpart[(size_t)g * p.C + SGBW_CH * blk + wave + 8 * lane] = dbv;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// r4: the batched 64 -> 64 weight gradients when EVERY operand is stored as split rows: the tiles go HBM -> LDS by
+// global_load_lds (no registers, no vector-pipe pass) into one of THREE tile buffers, two tiles ahead of the MFMAs -- the
+// register-staged kernel above has one tile in flight per work-group and both work-groups of a CU end up waiting for the same
+// ~2.5 us round trip behind a ~1.4 us MFMA phase (0.86 ms for the eleven layers, MFMA busy 57 %).  One work-group of EIGHT
+// waves per CU: wave (mi, ni, kh) owns the 32 x 32 block (mi, ni) of every tap for the K-steps 2 kh, 2 kh + 1 of each 64-row
+// tile, so the two waves of a SIMD work on the same tile; every (work-group, kh) writes one partial.
+// LDS rows are 256 bytes, unpadded, so that ONE copy instruction fills four rows (64 lanes x 16 bytes, consecutive in LDS; a
+// first form with the 320-byte row stride needed one 16-lane instruction per row: 134 per tile at the texture addresser's
+// 16 cycles each = as long as the tile's MFMAs -- 1.42 ms).  Bank conflicts of the transposing reads (a half-wave reads 64 bytes
+// of four consecutive rows) are avoided by a swizzle instead: 16-byte piece p of row R sits at slot p ^ ((R & 3) << 2); the copy
+// applies it on the global side (lane = slot fetches piece slot ^ ...), the readers through four precomputed lane offsets.
+// Rows outside the waveform are copied from a clamped address and zeroed after they land (first / last tile of a waveform only:
+// one more barrier).
+// ----------------------------------------------------------------------------------------------------------------
+// One copy (64 lanes x 16 bytes -> 1,024 consecutive LDS bytes at the wave-uniform address lds_addr) as inline assembly: behind
+// __builtin_amdgcn_global_load_lds the compiler puts s_waitcnt vmcnt(0) in front of the next LDS read it cannot prove disjoint --
+// i.e. in front of every tile's reads, which waits for the copies of the tile two ahead as well.  Hidden from its counters, these
+// copies only make the waits it inserts for its own loads more conservative; ours are the explicit vmcnt below.
+__device__ __forceinline__ void async_rows4(const float* src, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory", "m0");
+}
+constexpr int WA_NBUF = 3;
+constexpr int WA_ROWB = 256;
+constexpr int WA_XROWS = WG_ROWS_H + 8;
+constexpr int WA_BUF_BYTES = (WG_ROWS_H + WA_XROWS) * WA_ROWB;         // 34,816
+template <int K>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_split_async_kernel(const WgradBatch b) {
+    extern __shared__ __attribute__((aligned(16))) char wa_lds[];       // [WA_NBUF][dy: 64 rows | x: 72 rows][256 B, swizzled]
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = wave & 1, ni = (wave >> 1) & 1, kh = wave >> 2;
+    const int layer = blockIdx.y, G = gridDim.x, gx = blockIdx.x;
+    const float* const X = b.x[layer];
+    const float* const DY = b.dy[layer];
+    const int L = b.L, pad = K >> 1;
+    static_assert(K - 1 <= 8, "the x part of a tile buffer holds 64 + 8 rows");
+    constexpr int NI = (WG_ROWS_H + WA_XROWS) / 4;                      // copy instructions per tile: 16 of dy, 18 of x
+    floatx16 acc[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+    float dbh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // transposing reads: lane (q = row in the 4-row block, pq, cb, kg) reads 8 bytes = half `pq & 1` of piece 4 m + 2 cb + (pq >> 1)
+    // (m = mi for dy, ni for x; + 8: lo part) of row 8 kg + q (+ 4) + 16 ks + d; (row & 3) = (q + d) & 3
+    const int q = (lane & 15) >> 2, pq = lane & 3, cb = (lane >> 4) & 1, kg = lane >> 5;
+    auto lane_off = [&](int m, int j) {                                  // byte offset inside the row for swizzle (q + j) & 3, hi part
+        const int piece = 4 * m + 2 * cb + (pq >> 1);
+        return ((piece ^ (((q + j) & 3) << 2)) << 4) + 8 * (pq & 1);
+    };
+    const int arow = (8 * kg + q) * WA_ROWB;
+    const int aoff = arow + lane_off(mi, 0);
+    int boff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = WG_ROWS_H * WA_ROWB + arow + lane_off(ni, j);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)wa_lds);
+    // wave w issues copy instructions w, w + 8, ...: instruction g fills rows 4 g .. 4 g + 3 of the buffer
+    const int lrow = lane >> 4, slot = lane & 15;
+    auto issue = [&](int tile, int buf) {
+        const int n = tile / b.tiles_per_wf;
+        const int t0 = (tile - n * b.tiles_per_wf) * WG_ROWS_H;
+        const size_t wf = (size_t)n * L;
+#pragma unroll 1
+        for (int g = wave; g < NI; g += 8) {
+            const int R = 4 * g + lrow;
+            const bool isx = g >= WG_ROWS_H / 4;
+            int t = isx ? t0 - pad + (R - WG_ROWS_H) : t0 + R;
+            t = t < 0 ? 0 : (t > L - 1 ? L - 1 : t);
+            const int piece = slot ^ ((R & 3) << 2);
+            async_rows4((isx ? X : DY) + (wf + t) * 64 + 4 * piece, lds0 + buf * WA_BUF_BYTES + g * 4 * WA_ROWB);
+        }
+    };
+    constexpr int MINE_LO = NI / 8, REM = NI % 8;                      // waves < REM issue MINE_LO + 1 copies per tile
+    int tile = gx;
+    if (tile < b.total_tiles) issue(tile, 0);
+    if (tile + G < b.total_tiles) issue(tile + G, 1);
+    int buf = 0;
+    for (; tile < b.total_tiles; tile += G) {
+        // this wave's copies of `tile` have landed (those of the next tile stay in flight); the barrier extends that to every wave
+        // and says that everybody is done with the buffer the copies of tile + 2 G go to
+        if (tile + G < b.total_tiles) { if (wave < REM) wait_vm_lgkm0<MINE_LO + 1>(); else wait_vm_lgkm0<MINE_LO>(); }
+        else wait_vm_lgkm0<0>();
+        __builtin_amdgcn_s_barrier();
+        if (tile + 2 * G < b.total_tiles) issue(tile + 2 * G, buf == 0 ? 2 : buf - 1);
+        char* const base = wa_lds + buf * WA_BUF_BYTES;
+        const int n = tile / b.tiles_per_wf;
+        const int t0 = (tile - n * b.tiles_per_wf) * WG_ROWS_H;
+        if (t0 - pad < 0 || t0 + WG_ROWS_H + pad > L) {              // wave-uniform: rows before / behind the waveform are zero padding
+            for (int i = tid; i < (WG_ROWS_H + WG_ROWS_H + K - 1) * 16; i += 512) {
+                const int R = i >> 4;
+                const int t = R >= WG_ROWS_H ? t0 - pad + (R - WG_ROWS_H) : t0 + R;
+                if (t < 0 || t >= L) *reinterpret_cast<float4*>(base + R * WA_ROWB + 16 * (i & 15)) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+        }
+        // bias gradient: thread (row tid >> 4 (+ 32), slot tid & 15) sums the 8 halves of its slot (piece slot ^ swizzle(row):
+        // the same piece for both rows, 32 being a multiple of 4)
+#pragma unroll
+        for (int u = 0; u < WG_ROWS_H / 32; ++u) {
+            const float4 v = *reinterpret_cast<const float4*>(base + ((tid >> 4) + 32 * u) * WA_ROWB + 16 * (tid & 15));
+            const unsigned w4[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const half2v hv = bits_h2w(w4[e]);
+                dbh[2 * e] += (float)hv[0];
+                dbh[2 * e + 1] += (float)hv[1];
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int ks = 2 * kh + k2;
+            const char* a = base + aoff + ks * 16 * WA_ROWB;
+            const uint2 a0 = tr_read(a), a1 = tr_read(a + 4 * WA_ROWB);
+            const char* al_ = base + (aoff ^ 128) + ks * 16 * WA_ROWB;
+            const uint2 l0 = tr_read(al_), l1 = tr_read(al_ + 4 * WA_ROWB);
+            const uint4 ah = make_uint4(a0.x, a0.y, a1.x, a1.y), al = make_uint4(l0.x, l0.y, l1.x, l1.y);
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+                const char* bb = base + boff[d & 3] + (ks * 16 + d) * WA_ROWB;
+                const char* bl = base + (boff[d & 3] ^ 128) + (ks * 16 + d) * WA_ROWB;
+                const uint2 b0 = tr_read(bb), b1 = tr_read(bb + 4 * WA_ROWB);
+                const uint2 m0 = tr_read(bl), m1 = tr_read(bl + 4 * WA_ROWB);
+                acc[d] = mma16x3(ah, al, make_uint4(b0.x, b0.y, b1.x, b1.y), make_uint4(m0.x, m0.y, m1.x, m1.y), acc[d]);
+            }
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    // partial (work-group, kh): accumulator register v: row (o) = 32 mi + (v & 3) + 8 (v >> 2) + 4 lh, column (c) = 32 ni + ln
+    const int Gsets = 2 * G, set = 2 * gx + kh;
+    float* const part = b.part + ((size_t)layer * Gsets + set) * K * 64 * 64;
+    const int ln = lane & 31, lh = lane >> 5, c = 32 * ni + ln;
+#pragma unroll
+    for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int o = 32 * mi + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            part[((size_t)d * 64 + o) * 64 + c] = acc[d][v];
+        }
+    // bias gradient of the work-group -> set (gx, 0); set (gx, 1) holds zeros
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(wa_lds);
+    {
+        const int pc = (tid & 15) ^ (((tid >> 4) & 3) << 2);            // the piece behind the thread's slot
+        float* const o = red + (tid >> 4) * 128 + (pc >> 3) * 64 + 8 * (pc & 7);
+        *reinterpret_cast<float4*>(o) = make_float4(dbh[0], dbh[1], dbh[2], dbh[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(dbh[4], dbh[5], dbh[6], dbh[7]);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s += red[r * 128 + tid] + red[r * 128 + 64 + tid];
+        float* const dbp = b.dbpart + ((size_t)layer * Gsets + 2 * gx) * 64;
+        dbp[tid] = s;
+        dbp[64 + tid] = 0.f;
+    }
+}
+
 // orders a wave's LDS accesses for the compiler (the hardware executes one wave's LDS instructions in order)
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1633,6 +1793,19 @@ __global__ __launch_bounds__(256) void add_split_kernel(const float* __restrict_
     *reinterpret_cast<float4*>(o + 4) = make_float4(v[4] + b1.x, v[5] + b1.y, v[6] + b1.z, v[7] + b1.w);
 }
 
+// fp32 rows [rows][64] -> split rows (thread = row, 4 channels)
+__global__ __launch_bounds__(256) void to_split_rows_kernel(const float* __restrict__ in, float* __restrict__ out, long long rows) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= rows * 16) return;
+    const long long r = i >> 4;
+    const int qq = (int)(i & 15);
+    uint2 hi, lo;
+    split4(ld4(in + r * 64 + 4 * qq), hi, lo);
+    char* const o = reinterpret_cast<char*>(out + r * 64);
+    *reinterpret_cast<uint2*>(o + 8 * qq) = hi;
+    *reinterpret_cast<uint2*>(o + 128 + 8 * qq) = lo;
+}
+
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -1822,6 +1995,20 @@ static int wgrad_batch_impl(const float* const* x, const float* const* dy, float
     int G = wgrad_batch_groups(count);
     if (G > tiles) G = (int)tiles;
     b.part = static_cast<float*>(workspace);
+    const unsigned all = count >= 32 ? 0xffffffffu : ((1u << count) - 1u);
+    static const bool async_on = [] { const char* e = getenv("STOF_TRAIN_WGRAD_ASYNC"); return e == nullptr || e[0] != '0'; }();
+    if (async_on && K == 7 && (x_split & all) == all && (dy_split & all) == all && G >= 2 && (G & 1) == 0) {
+        // every operand is split rows: the global_load_lds kernel, G / 2 work-groups of eight waves per layer, G partials as before
+        const int Gw = G / 2;
+        b.dbpart = b.part + (size_t)count * G * K * 64 * 64;
+        static stof::LdsLimitOnce once;
+        constexpr int lds_bytes = WA_NBUF * WA_BUF_BYTES;
+        if (int st = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_split_async_kernel<7>), lds_bytes)) return st;
+        hipLaunchKernelGGL(conv_wgrad_split_async_kernel<7>, dim3((unsigned)Gw, (unsigned)count, 1), dim3(512), lds_bytes, s, b);
+        const int total7 = K * 64 * 64 + 64;
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((total7 + 63) / 64, (unsigned)count), dim3(64 * WRED_SLICES), 0, s, b, G);
+        return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+    }
     b.dbpart = b.part + (size_t)count * G * K * 64 * 64;
     const dim3 grid((unsigned)G, (unsigned)count, 1);
     if (K == 3) hipLaunchKernelGGL(conv_wgrad_f16x3_batch_kernel<3>, grid, dim3(256), 0, s, b);
@@ -1844,6 +2031,16 @@ extern "C" int stof_train_wgrad_batch_split(const float* const* x, const float* 
         if ((((x_split >> i) & 1u) && x && (reinterpret_cast<size_t>(x[i]) & 15)) ||
             (((dy_split >> i) & 1u) && dy && (reinterpret_cast<size_t>(dy[i]) & 15))) return STOF_ERR_BAD_ARG;      // 16-byte pieces
     return wgrad_batch_impl(x, dy, dw, db, count, N, L, K, out_scale, workspace, workspace_bytes, stream, x_split, dy_split);
+}
+
+// fp32 rows [rows][64] -> split rows [64 x fp16 hi | 64 x fp16 lo] (conv12's output gradient for stof_train_wgrad_batch_split)
+extern "C" int stof_train_to_split_rows(const float* in, float* out, int64_t rows, void* stream) {
+    if (rows < 0) return STOF_ERR_BAD_ARG;
+    if (rows == 0) return STOF_OK;
+    if (!in || !out || ((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out)) & 15)) return STOF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(to_split_rows_kernel, dim3(blocks_for(rows * 16)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
+                       (long long)rows);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 
 // out = (hi + lo of the split rows a) + b   (the backward sweep's dL/dx_0 is a split-row tensor; the long skip adds the fp32 g6)

@@ -285,12 +285,16 @@ class TrainEngine:
                     ws = self._wgrad_batch_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
                 arr = lambda ts: (ctypes.c_void_p * cnt)(*[_lib.ptr(t) for t in ts])
                 if split:
-                    # every x operand is a forward dump tensor (0..10) and every dy a backward dump tensor, except conv12's dy = g6 (fp32)
+                    # every x operand is a forward dump tensor (0..10) and every dy a backward dump tensor, except conv12's dy = g6
+                    # (fp32, from conv_last's data gradient): converted once, so that the launch takes the all-split kernel
                     all_bits = (1 << cnt) - 1
+                    g6s = torch.empty_like(g6)
+                    _lib.check(lib.stof_train_to_split_rows(_lib.ptr(g6), _lib.ptr(g6s), n * L, st), 'stof_train_to_split_rows')
+                    pairs[0] = (pairs[0][0], g6s, pairs[0][2])
                     _lib.check(lib.stof_train_wgrad_batch_split(arr([a for a, _, _ in pairs]), arr([d for _, d, _ in pairs]),
                                                                 arr([self.g[nm + '.weight'] for _, _, nm in pairs]),
                                                                 arr([self.g[nm + '.bias'] for _, _, nm in pairs]), cnt, all_bits,
-                                                                all_bits & ~1, n, L, 7, 1.0 / self._gscale, _lib.ptr(ws), ws.numel(), st),
+                                                                all_bits, n, L, 7, 1.0 / self._gscale, _lib.ptr(ws), ws.numel(), st),
                                'stof_train_wgrad_batch_split')
                 else:
                     _lib.check(lib.stof_train_wgrad_batch(arr([a for a, _, _ in pairs]), arr([d for _, d, _ in pairs]),
