@@ -1033,16 +1033,19 @@ __global__ __launch_bounds__(512, 4) void sgb_contract_wgrad_kernel(const SgbWgr
 __device__ __forceinline__ void async_rows4(const float* src, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory", "m0");
 }
-constexpr int WA_NBUF = 3;
 constexpr int WA_ROWB = 256;
 constexpr int WA_XROWS = WG_ROWS_H + 8;
 constexpr int WA_BUF_BYTES = (WG_ROWS_H + WA_XROWS) * WA_ROWB;         // 34,816
-template <int K>
-__global__ __launch_bounds__(512, 1) void conv_wgrad_split_async_kernel(const WgradBatch b) {
+// KH = 2: eight waves per work-group, one work-group per CU, three buffers (copies two tiles ahead); KH = 1: four waves (every
+// wave runs all four K-steps of a tile), two work-groups per CU with two buffers each (copies one tile ahead), whose phases
+// drift apart so that one group's barrier / first-read bubble is filled by the other's MFMAs.
+template <int K, int KH>
+__global__ __launch_bounds__(256 * KH, 3 - KH) void conv_wgrad_split_async_kernel(const WgradBatch b) {
+    constexpr int NW = 4 * KH, NT = 64 * NW, NBUF = KH + 1;
     extern __shared__ __attribute__((aligned(16))) char wa_lds[];       // [WA_NBUF][dy: 64 rows | x: 72 rows][256 B, swizzled]
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mi = wave & 1, ni = (wave >> 1) & 1, kh = wave >> 2;
+    const int mi = wave & 1, ni = (wave >> 1) & 1, kh = wave >> 2;       // (kh = 0 for KH = 1)
     const int layer = blockIdx.y, G = gridDim.x, gx = blockIdx.x;
     const float* const X = b.x[layer];
     const float* const DY = b.dy[layer];
@@ -1071,11 +1074,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_async_kernel(const Wg
     // wave w issues copy instructions w, w + 8, ...: instruction g fills rows 4 g .. 4 g + 3 of the buffer
     const int lrow = lane >> 4, slot = lane & 15;
     auto issue = [&](int tile, int buf) {
+#ifdef WA_EXP_L2
+        tile = gx;                                  // timing experiment: every tile re-reads the first one (L2 hits, no HBM traffic)
+#endif
         const int n = tile / b.tiles_per_wf;
         const int t0 = (tile - n * b.tiles_per_wf) * WG_ROWS_H;
         const size_t wf = (size_t)n * L;
 #pragma unroll 1
-        for (int g = wave; g < NI; g += 8) {
+        for (int g = wave; g < NI; g += NW) {
             const int R = 4 * g + lrow;
             const bool isx = g >= WG_ROWS_H / 4;
             int t = isx ? t0 - pad + (R - WG_ROWS_H) : t0 + R;
@@ -1084,23 +1090,24 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_async_kernel(const Wg
             async_rows4((isx ? X : DY) + (wf + t) * 64 + 4 * piece, lds0 + buf * WA_BUF_BYTES + g * 4 * WA_ROWB);
         }
     };
-    constexpr int MINE_LO = NI / 8, REM = NI % 8;                      // waves < REM issue MINE_LO + 1 copies per tile
+    constexpr int MINE_LO = NI / NW, REM = NI % NW;                    // waves < REM issue MINE_LO + 1 copies per tile
     int tile = gx;
     if (tile < b.total_tiles) issue(tile, 0);
-    if (tile + G < b.total_tiles) issue(tile + G, 1);
+    if (KH == 2 && tile + G < b.total_tiles) issue(tile + G, 1);
     int buf = 0;
     for (; tile < b.total_tiles; tile += G) {
-        // this wave's copies of `tile` have landed (those of the next tile stay in flight); the barrier extends that to every wave
-        // and says that everybody is done with the buffer the copies of tile + 2 G go to
-        if (tile + G < b.total_tiles) { if (wave < REM) wait_vm_lgkm0<MINE_LO + 1>(); else wait_vm_lgkm0<MINE_LO>(); }
+        // this wave's copies of `tile` have landed (KH = 2: those of the next tile stay in flight); the barrier extends that to every
+        // wave and says that everybody is done with the buffer the next copies go to
+        if (KH == 2 && tile + G < b.total_tiles) { if (wave < REM) wait_vm_lgkm0<MINE_LO + 1>(); else wait_vm_lgkm0<MINE_LO>(); }
         else wait_vm_lgkm0<0>();
         __builtin_amdgcn_s_barrier();
-        if (tile + 2 * G < b.total_tiles) issue(tile + 2 * G, buf == 0 ? 2 : buf - 1);
+        if (KH == 2) { if (tile + 2 * G < b.total_tiles) issue(tile + 2 * G, buf == 0 ? 2 : buf - 1); }
+        else if (tile + G < b.total_tiles) issue(tile + G, buf ^ 1);
         char* const base = wa_lds + buf * WA_BUF_BYTES;
         const int n = tile / b.tiles_per_wf;
         const int t0 = (tile - n * b.tiles_per_wf) * WG_ROWS_H;
         if (t0 - pad < 0 || t0 + WG_ROWS_H + pad > L) {              // wave-uniform: rows before / behind the waveform are zero padding
-            for (int i = tid; i < (WG_ROWS_H + WG_ROWS_H + K - 1) * 16; i += 512) {
+            for (int i = tid; i < (WG_ROWS_H + WG_ROWS_H + K - 1) * 16; i += NT) {
                 const int R = i >> 4;
                 const int t = R >= WG_ROWS_H ? t0 - pad + (R - WG_ROWS_H) : t0 + R;
                 if (t < 0 || t >= L) *reinterpret_cast<float4*>(base + R * WA_ROWB + 16 * (i & 15)) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1111,8 +1118,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_async_kernel(const Wg
         // bias gradient: thread (row tid >> 4 (+ 32), slot tid & 15) sums the 8 halves of its slot (piece slot ^ swizzle(row):
         // the same piece for both rows, 32 being a multiple of 4)
 #pragma unroll
-        for (int u = 0; u < WG_ROWS_H / 32; ++u) {
-            const float4 v = *reinterpret_cast<const float4*>(base + ((tid >> 4) + 32 * u) * WA_ROWB + 16 * (tid & 15));
+        for (int u = 0; u < WG_ROWS_H / (NT / 16); ++u) {
+            const float4 v = *reinterpret_cast<const float4*>(base + ((tid >> 4) + (NT / 16) * u) * WA_ROWB + 16 * (tid & 15));
             const unsigned w4[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1122,26 +1129,46 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_async_kernel(const Wg
             }
         }
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            const int ks = 2 * kh + k2;
+        for (int k2 = 0; k2 < 4 / KH; ++k2) {
+            const int ks = (4 / KH) * kh + k2;
             const char* a = base + aoff + ks * 16 * WA_ROWB;
             const uint2 a0 = tr_read(a), a1 = tr_read(a + 4 * WA_ROWB);
             const char* al_ = base + (aoff ^ 128) + ks * 16 * WA_ROWB;
             const uint2 l0 = tr_read(al_), l1 = tr_read(al_ + 4 * WA_ROWB);
             const uint4 ah = make_uint4(a0.x, a0.y, a1.x, a1.y), al = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            // the taps' MFMAs part by part (hi*hi of every tap, then hi*lo, then lo*hi): consecutive MFMAs never accumulate into the
+            // same registers (a chain of three on one accumulator left the pipe idle between them); per accumulator the order of the
+            // three products is unchanged
+            uint4 bh[K], bl[K];
 #pragma unroll
             for (int d = 0; d < K; ++d) {
                 const char* bb = base + boff[d & 3] + (ks * 16 + d) * WA_ROWB;
-                const char* bl = base + (boff[d & 3] ^ 128) + (ks * 16 + d) * WA_ROWB;
+                const char* bq = base + (boff[d & 3] ^ 128) + (ks * 16 + d) * WA_ROWB;
+#ifdef WA_EXP_NOB                                                        // timing experiment: no operand reads at all (results are garbage)
+                (void)bb; (void)bq;
+                bh[d] = make_uint4(0x3c003c00u + lane, 0x3c003c00u + d, 0x3c003c00u + ks, 0x3c003c00u);
+                bl[d] = make_uint4(0x1c001c00u + lane, 0x1c001c00u + d, 0x1c001c00u + ks, 0x1c001c00u);
+#else
                 const uint2 b0 = tr_read(bb), b1 = tr_read(bb + 4 * WA_ROWB);
-                const uint2 m0 = tr_read(bl), m1 = tr_read(bl + 4 * WA_ROWB);
-                acc[d] = mma16x3(ah, al, make_uint4(b0.x, b0.y, b1.x, b1.y), make_uint4(m0.x, m0.y, m1.x, m1.y), acc[d]);
+                const uint2 m0 = tr_read(bq), m1 = tr_read(bq + 4 * WA_ROWB);
+                bh[d] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                bl[d] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+#endif
             }
+            union U { uint4 u; half8 h; };
+            U uah, ual;
+            uah.u = ah; ual.u = al;
+#pragma unroll
+            for (int d = 0; d < K; ++d) { U ub; ub.u = bh[d]; acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uah.h, ub.h, acc[d], 0, 0, 0); }
+#pragma unroll
+            for (int d = 0; d < K; ++d) { U ub; ub.u = bl[d]; acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uah.h, ub.h, acc[d], 0, 0, 0); }
+#pragma unroll
+            for (int d = 0; d < K; ++d) { U ub; ub.u = bh[d]; acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ual.h, ub.h, acc[d], 0, 0, 0); }
         }
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
     }
     // partial (work-group, kh): accumulator register v: row (o) = 32 mi + (v & 3) + 8 (v >> 2) + 4 lh, column (c) = 32 ni + ln
-    const int Gsets = 2 * G, set = 2 * gx + kh;
+    const int Gsets = KH * G, set = KH * gx + kh;
     float* const part = b.part + ((size_t)layer * Gsets + set) * K * 64 * 64;
     const int ln = lane & 31, lh = lane >> 5, c = 32 * ni + ln;
 #pragma unroll
@@ -1164,10 +1191,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_async_kernel(const Wg
     if (tid < 64) {
         float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) s += red[r * 128 + tid] + red[r * 128 + 64 + tid];
-        float* const dbp = b.dbpart + ((size_t)layer * Gsets + 2 * gx) * 64;
+        for (int r = 0; r < NT / 16; ++r) s += red[r * 128 + tid] + red[r * 128 + 64 + tid];
+        float* const dbp = b.dbpart + ((size_t)layer * Gsets + KH * gx) * 64;
         dbp[tid] = s;
-        dbp[64 + tid] = 0.f;
+        if (KH == 2) dbp[64 + tid] = 0.f;
     }
 }
 
@@ -1996,15 +2023,23 @@ static int wgrad_batch_impl(const float* const* x, const float* const* dy, float
     if (G > tiles) G = (int)tiles;
     b.part = static_cast<float*>(workspace);
     const unsigned all = count >= 32 ? 0xffffffffu : ((1u << count) - 1u);
-    static const bool async_on = [] { const char* e = getenv("STOF_TRAIN_WGRAD_ASYNC"); return e == nullptr || e[0] != '0'; }();
-    if (async_on && K == 7 && (x_split & all) == all && (dy_split & all) == all && G >= 2 && (G & 1) == 0) {
+    // STOF_TRAIN_WGRAD_ASYNC (read per call: tests switch it): unset / 1 = the four-wave global_load_lds kernel, 2 = its eight-wave
+    // form, 0 = the register-staged kernel
+    const char* const aenv = getenv("STOF_TRAIN_WGRAD_ASYNC");
+    const int form = aenv ? atoi(aenv) : 1;
+    if (form != 0 && K == 7 && (x_split & all) == all && (dy_split & all) == all && G >= 2 && (G & 1) == 0) {
         // every operand is split rows: the global_load_lds kernel, G / 2 work-groups of eight waves per layer, G partials as before
-        const int Gw = G / 2;
         b.dbpart = b.part + (size_t)count * G * K * 64 * 64;
-        static stof::LdsLimitOnce once;
-        constexpr int lds_bytes = WA_NBUF * WA_BUF_BYTES;
-        if (int st = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_split_async_kernel<7>), lds_bytes)) return st;
-        hipLaunchKernelGGL(conv_wgrad_split_async_kernel<7>, dim3((unsigned)Gw, (unsigned)count, 1), dim3(512), lds_bytes, s, b);
+        static stof::LdsLimitOnce once[2];
+        if (form == 2) {
+            constexpr int lds_bytes = 3 * WA_BUF_BYTES;
+            if (int st = once[0].ensure(reinterpret_cast<const void*>(&conv_wgrad_split_async_kernel<7, 2>), lds_bytes)) return st;
+            hipLaunchKernelGGL((conv_wgrad_split_async_kernel<7, 2>), dim3((unsigned)(G / 2), (unsigned)count, 1), dim3(512), lds_bytes, s, b);
+        } else {
+            constexpr int lds_bytes = 2 * WA_BUF_BYTES;
+            if (int st = once[1].ensure(reinterpret_cast<const void*>(&conv_wgrad_split_async_kernel<7, 1>), lds_bytes)) return st;
+            hipLaunchKernelGGL((conv_wgrad_split_async_kernel<7, 1>), dim3((unsigned)G, (unsigned)count, 1), dim3(256), lds_bytes, s, b);
+        }
         const int total7 = K * 64 * 64 + 64;
         hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((total7 + 63) / 64, (unsigned)count), dim3(64 * WRED_SLICES), 0, s, b, G);
         return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
