@@ -507,8 +507,8 @@ def run_extra_configs(args):
     sample; its line is distilled to {value, ms_per_step, roofline, parity_on_sample, ...}."""
     runs = [('C3', ['--config', 'C3', '--steps', '5', '--warmup', '1']),
             ('C4', ['--config', 'C4', '--steps', '2', '--warmup', '1']),
-            ('C5', ['--config', 'C5', '--steps', '20', '--warmup', '3']),
-            ('C5_batch4', ['--config', 'C5', '--steps', '20', '--warmup', '3', '--rows', '4'])]
+            ('C5', ['--config', 'C5', '--steps', '50', '--warmup', '5']),
+            ('C5_batch4', ['--config', 'C5', '--steps', '50', '--warmup', '5', '--rows', '4'])]
     out = {}
     for name, extra in runs:
         cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-extra-configs', '--no-fp32-extra',
