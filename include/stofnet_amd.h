@@ -406,7 +406,8 @@ int stof_train_loss_target(const int64_t* gt_idx, int64_t G, const float* taps7,
 int stof_train_loss_grad(const float* pred, float* target, const float* tmax, int64_t N, int64_t M, float amplitude,
                          float lambda, float grad_scale, float* dpred, double* loss, void* stream);
 /* stof_train_sweep_bwd on a forward dump written by stof_train_sweep_split (the leaky-ReLU derivative is read off the sign of the
- * saved activation's hi half: an activation with |y| < 2^-25 counts as not positive), all eleven output tensors as split rows. */
+ * saved activation's hi half: an activation with |y| < 2^-25 counts as not positive), all eleven output tensors as split rows;
+ * g6 is a split-row tensor too (stof_train_conv_last_dgrad_split or stof_train_to_split_rows).                              */
 int stof_train_sweep_bwd_split(const stof_net_desc* desc, const void* blob_dev, const float* g6, const float* fwd_dump,
                                float* dump, int64_t N, int64_t L, void* stream);
 /* fp32 rows in[rows][64] -> split rows out (conv12's output gradient g6, so that every operand of
@@ -414,6 +415,11 @@ int stof_train_sweep_bwd_split(const stof_net_desc* desc, const void* blob_dev, 
 int stof_train_to_split_rows(const float* in, float* out, int64_t rows, void* stream);
 /* out[rows][64] = (hi + lo of the split rows a_split) + b  (the long-skip join on the backward sweep's split-row dL/dx_0).  */
 int stof_train_add_split(const float* a_split, const float* b, float* out, int64_t rows, void* stream);
+/* The same with b a split-row tensor as well.                                                                              */
+int stof_train_add_split2(const float* a_split, const float* b_split, float* out, int64_t rows, void* stream);
+/* stof_train_conv_last_dgrad with out written as split rows: the g6 operand of stof_train_sweep_bwd_split (which expects its g6
+ * as split rows) and of stof_train_wgrad_batch_split.                                                                      */
+int stof_train_conv_last_dgrad_split(const float* dz, const float* weight, float* out, int64_t N, int64_t L, int32_t r, void* stream);
 /* out = a + b (gradient joins of the residual / long-skip branches, models/stofnet.py:56,62).         */
 int stof_train_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* torch.optim.AdamW step on one flat parameter vector (main.py:179,248).                             */

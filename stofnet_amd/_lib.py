@@ -135,6 +135,8 @@ _SIGNATURES = {
     'stof_train_add': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
     'stof_train_add_split': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
     'stof_train_to_split_rows': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
+    'stof_train_add_split2': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
+    'stof_train_conv_last_dgrad_split': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p]),
     'stof_train_sweep_split': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
     'stof_train_sweep_bwd_split': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
     'stof_train_wgrad_batch_split': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_uint32, _c.c_uint32, _c.c_int64,

@@ -277,10 +277,28 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
             int nw, tw;
             vmap(n0 + nl, t, nw, tw);
             const bool ok = (g >= 0) && (g < gend) && (t < L) && (tw >= 0) && (tw < Ltrue);
-            v[it] = ok ? ld4(p.gin + ((size_t)nw * Ltrue + tw) * NF + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (HL) {
+                // g6 arrives as split rows: the thread's 4 channels are 8 bytes of the hi part and 8 of the lo part -- the ring's own layout
+                if (ok) {
+                    const char* const row = reinterpret_cast<const char*>(p.gin + ((size_t)nw * Ltrue + tw) * NF);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(row + 8 * cq), lo = *reinterpret_cast<const uint2*>(row + 128 + 8 * cq);
+                    v[it] = make_float4(__uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(lo.x), __uint_as_float(lo.y));
+                }
+            } else if (ok) {
+                v[it] = ld4(p.gin + ((size_t)nw * Ltrue + tw) * NF + 4 * cq);
+            }
         }
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) store_act4<PREC>(dst + ((g0 + it) & (RING - 1)) * ROWB, 4 * cq, v[it]);
+        for (int it = 0; it < NIT; ++it) {
+            char* const row = dst + ((g0 + it) & (RING - 1)) * ROWB;
+            if constexpr (HL) {
+                *reinterpret_cast<uint2*>(row + 8 * cq) = make_uint2(__float_as_uint(v[it].x), __float_as_uint(v[it].y));
+                *reinterpret_cast<uint2*>(row + 128 + 8 * cq) = make_uint2(__float_as_uint(v[it].z), __float_as_uint(v[it].w));
+            } else {
+                store_act4<PREC>(row, 4 * cq, v[it]);
+            }
+        }
     };
 
     // ---- weights: two half-layer buffers of 7 chunks x 4 fragments (M-tile 0 hi | lo, M-tile 1 hi | lo), see the header

@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(64 * WRED_SLICES) void sgb_wgrad_reduce_kernel(cons
 // thread = (channel quad, row lane) keeps its 3 x R x 4 weights in registers and walks 16 rows, the dz rows come from LDS.
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int CLD_ROWS = 256;
-template <int R>
+template <int R, bool SPLIT = false>          // SPLIT: the rows are written as split rows [64 x fp16 hi | 64 x fp16 lo]
 __global__ __launch_bounds__(256) void conv_last_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
                                                               float* __restrict__ out, int N, int L) {
     constexpr int RP = (R + 3) / 4 * 4;                           // floats per staged row
@@ -1453,7 +1453,15 @@ __global__ __launch_bounds__(256) void conv_last_dgrad_kernel(const float* __res
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = fmaf(z[o], wr[d][o][e], acc[e]);
         }
-        *reinterpret_cast<float4*>(out + (n * L + t) * 64 + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if constexpr (SPLIT) {
+            uint2 hi, lo;
+            split4(make_float4(acc[0], acc[1], acc[2], acc[3]), hi, lo);
+            char* const o = reinterpret_cast<char*>(out + (n * L + t) * 64);
+            *reinterpret_cast<uint2*>(o + 8 * q) = hi;
+            *reinterpret_cast<uint2*>(o + 128 + 8 * q) = lo;
+        } else {
+            *reinterpret_cast<float4*>(out + (n * L + t) * 64 + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
     }
 }
 
@@ -1798,6 +1806,7 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
 }
 
 // thread = (row, piece p of 8): channels 8 p .. 8 p + 7 = hi piece p + lo piece p of the split row, plus b's two float4
+template <bool BSPLIT>                     // BSPLIT: b is a split-row tensor too
 __global__ __launch_bounds__(256) void add_split_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                         float* __restrict__ out, long long rows) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;
@@ -1814,7 +1823,24 @@ __global__ __launch_bounds__(256) void add_split_kernel(const float* __restrict_
         v[2 * e] = (float)h[0] + (float)l[0];
         v[2 * e + 1] = (float)h[1] + (float)l[1];
     }
-    const float4 b0 = ld4(b + r * 64 + 8 * pc), b1 = ld4(b + r * 64 + 8 * pc + 4);
+    float4 b0, b1;
+    if constexpr (BSPLIT) {
+        const float4 bh = ld4(b + r * 64 + 4 * pc), bl = ld4(b + r * 64 + 32 + 4 * pc);
+        const unsigned bhw[4] = {__float_as_uint(bh.x), __float_as_uint(bh.y), __float_as_uint(bh.z), __float_as_uint(bh.w)};
+        const unsigned blw[4] = {__float_as_uint(bl.x), __float_as_uint(bl.y), __float_as_uint(bl.z), __float_as_uint(bl.w)};
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const half2v h = bits_h2w(bhw[e]), l = bits_h2w(blw[e]);
+            w[2 * e] = (float)h[0] + (float)l[0];
+            w[2 * e + 1] = (float)h[1] + (float)l[1];
+        }
+        b0 = make_float4(w[0], w[1], w[2], w[3]);
+        b1 = make_float4(w[4], w[5], w[6], w[7]);
+    } else {
+        b0 = ld4(b + r * 64 + 8 * pc);
+        b1 = ld4(b + r * 64 + 8 * pc + 4);
+    }
     float* const o = out + r * 64 + 8 * pc;
     *reinterpret_cast<float4*>(o) = make_float4(v[0] + b0.x, v[1] + b0.y, v[2] + b0.z, v[3] + b0.w);
     *reinterpret_cast<float4*>(o + 4) = make_float4(v[4] + b1.x, v[5] + b1.y, v[6] + b1.z, v[7] + b1.w);
@@ -2079,14 +2105,25 @@ extern "C" int stof_train_to_split_rows(const float* in, float* out, int64_t row
 }
 
 // out = (hi + lo of the split rows a) + b   (the backward sweep's dL/dx_0 is a split-row tensor; the long skip adds the fp32 g6)
-extern "C" int stof_train_add_split(const float* a_split, const float* b, float* out, int64_t rows, void* stream) {
+static int add_split_impl(const float* a_split, const float* b, float* out, int64_t rows, void* stream, bool b_split) {
     if (rows < 0) return STOF_ERR_BAD_ARG;
     if (rows == 0) return STOF_OK;
     if (!a_split || !b || !out) return STOF_ERR_BAD_ARG;
     if ((reinterpret_cast<size_t>(a_split) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(out)) & 15) return STOF_ERR_BAD_ARG;
-    hipLaunchKernelGGL(add_split_kernel, dim3(blocks_for(rows * 8)), dim3(256), 0, static_cast<hipStream_t>(stream), a_split, b, out,
-                       (long long)rows);
+    if (b_split)
+        hipLaunchKernelGGL(add_split_kernel<true>, dim3(blocks_for(rows * 8)), dim3(256), 0, static_cast<hipStream_t>(stream), a_split, b, out,
+                           (long long)rows);
+    else
+        hipLaunchKernelGGL(add_split_kernel<false>, dim3(blocks_for(rows * 8)), dim3(256), 0, static_cast<hipStream_t>(stream), a_split, b, out,
+                           (long long)rows);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+extern "C" int stof_train_add_split(const float* a_split, const float* b, float* out, int64_t rows, void* stream) {
+    return add_split_impl(a_split, b, out, rows, stream, false);
+}
+// out = (a_split) + (b_split), both split-row tensors, out fp32
+extern "C" int stof_train_add_split2(const float* a_split, const float* b_split, float* out, int64_t rows, void* stream) {
+    return add_split_impl(a_split, b_split, out, rows, stream, true);
 }
 
 extern "C" int stof_train_conv1(const float* x, const float* w, const float* b, float* y, int64_t N, int64_t L, void* stream) {
@@ -2221,7 +2258,7 @@ extern "C" int stof_train_sgb_contract_dgrad(const float* gpool, const uint8_t* 
 
 // Data gradient of conv_last: out[N, L, 64] from dz[N, L, r] and conv_last.weight[r][64][3] (exact fp32).  r = 4 or 10;
 // other factors return STOF_ERR_UNSUPPORTED (the caller uses stof_train_conv with the repacked weights).
-extern "C" int stof_train_conv_last_dgrad(const float* dz, const float* weight, float* out, int64_t N, int64_t L, int32_t r, void* stream) {
+static int conv_last_dgrad_impl(const float* dz, const float* weight, float* out, int64_t N, int64_t L, int32_t r, void* stream, bool split) {
     if (N < 0 || L < 0 || r < 1) return STOF_ERR_BAD_ARG;
     if (r != 4 && r != 10) return STOF_ERR_UNSUPPORTED;
     if (N == 0 || L == 0) return STOF_OK;
@@ -2229,9 +2266,21 @@ extern "C" int stof_train_conv_last_dgrad(const float* dz, const float* weight, 
     const int64_t groups = N * ((L + CLD_ROWS - 1) / CLD_ROWS);
     if (groups > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (r == 10) hipLaunchKernelGGL(conv_last_dgrad_kernel<10>, dim3((unsigned)groups), dim3(256), 0, s, dz, weight, out, (int)N, (int)L);
-    else hipLaunchKernelGGL(conv_last_dgrad_kernel<4>, dim3((unsigned)groups), dim3(256), 0, s, dz, weight, out, (int)N, (int)L);
+    if (split) {
+        if (r == 10) hipLaunchKernelGGL((conv_last_dgrad_kernel<10, true>), dim3((unsigned)groups), dim3(256), 0, s, dz, weight, out, (int)N, (int)L);
+        else hipLaunchKernelGGL((conv_last_dgrad_kernel<4, true>), dim3((unsigned)groups), dim3(256), 0, s, dz, weight, out, (int)N, (int)L);
+    } else {
+        if (r == 10) hipLaunchKernelGGL(conv_last_dgrad_kernel<10>, dim3((unsigned)groups), dim3(256), 0, s, dz, weight, out, (int)N, (int)L);
+        else hipLaunchKernelGGL(conv_last_dgrad_kernel<4>, dim3((unsigned)groups), dim3(256), 0, s, dz, weight, out, (int)N, (int)L);
+    }
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+extern "C" int stof_train_conv_last_dgrad(const float* dz, const float* weight, float* out, int64_t N, int64_t L, int32_t r, void* stream) {
+    return conv_last_dgrad_impl(dz, weight, out, N, L, r, stream, false);
+}
+// the same with out[N, L] written as split rows (stof_train_sweep_bwd_split and stof_train_wgrad_batch_split read it as such)
+extern "C" int stof_train_conv_last_dgrad_split(const float* dz, const float* weight, float* out, int64_t N, int64_t L, int32_t r, void* stream) {
+    return conv_last_dgrad_impl(dz, weight, out, N, L, r, stream, true);
 }
 
 extern "C" int stof_train_upsample_add(const float* a, const float* e, float* out, int64_t N, int64_t L, int64_t P,

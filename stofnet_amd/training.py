@@ -244,12 +244,18 @@ class TrainEngine:
         self._wgrad(x6, dz, 'conv_last', 64, r, 3)
         # conv_last's data gradient: r input channels would be padded to a 64-channel block by the layer kernels
         g6 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
-        code = lib.stof_train_conv_last_dgrad(_lib.ptr(dz.contiguous()), _lib.ptr(saved['wl'].contiguous()), _lib.ptr(g6), n, L, r, st)
+        split = bool(saved.get('split'))          # the forward dumps are split rows: only the sweep + batched route reads them
+        # split route: g6 is a split-row tensor as well (the backward sweep's input, conv12's output gradient for the weight-gradient
+        # launch and the long-skip join all take it as such)
+        code = (lib.stof_train_conv_last_dgrad_split if split else lib.stof_train_conv_last_dgrad)(
+            _lib.ptr(dz.contiguous()), _lib.ptr(saved['wl'].contiguous()), _lib.ptr(g6), n, L, r, st)
         if code == _lib.STOF_ERR_UNSUPPORTED:
             g6 = self._conv(dz, bwd['conv_last'], None, r, 64, 3)
+            if split:
+                g6f, g6 = g6, torch.empty_like(g6)
+                _lib.check(lib.stof_train_to_split_rows(_lib.ptr(g6f), _lib.ptr(g6), n * L, st), 'stof_train_to_split_rows')
         else:
             _lib.check(code, 'stof_train_conv_last_dgrad')
-        split = bool(saved.get('split'))          # the forward dumps are split rows: only the sweep + batched route reads them
         batch_wgrad = (self.prec == 1 and saved.get('_dump') is not None and 'conv12' not in bwd
                        and (split or os.environ.get('STOF_TRAIN_WGRAD_BATCH', '1') != '0'))
         if split and not batch_wgrad:
@@ -285,12 +291,8 @@ class TrainEngine:
                     ws = self._wgrad_batch_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
                 arr = lambda ts: (ctypes.c_void_p * cnt)(*[_lib.ptr(t) for t in ts])
                 if split:
-                    # every x operand is a forward dump tensor (0..10) and every dy a backward dump tensor, except conv12's dy = g6
-                    # (fp32, from conv_last's data gradient): converted once, so that the launch takes the all-split kernel
+                    # every x operand is a forward dump tensor (0..10), every dy a backward dump tensor or g6: all split rows
                     all_bits = (1 << cnt) - 1
-                    g6s = torch.empty_like(g6)
-                    _lib.check(lib.stof_train_to_split_rows(_lib.ptr(g6), _lib.ptr(g6s), n * L, st), 'stof_train_to_split_rows')
-                    pairs[0] = (pairs[0][0], g6s, pairs[0][2])
                     _lib.check(lib.stof_train_wgrad_batch_split(arr([a for a, _, _ in pairs]), arr([d for _, d, _ in pairs]),
                                                                 arr([self.g[nm + '.weight'] for _, _, nm in pairs]),
                                                                 arr([self.g[nm + '.bias'] for _, _, nm in pairs]), cnt, all_bits,
@@ -315,7 +317,7 @@ class TrainEngine:
                 gg = self._conv(u, bwd[na], None, 64, 64, 7, residual=gg)             # d/dx_k
         if split:                                                                 # long skip res1 (models/stofnet.py:62)
             g_x0 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
-            _lib.check(lib.stof_train_add_split(_lib.ptr(gg), _lib.ptr(g6), _lib.ptr(g_x0), n * L, st), 'stof_train_add_split')
+            _lib.check(lib.stof_train_add_split2(_lib.ptr(gg), _lib.ptr(g6), _lib.ptr(g_x0), n * L, st), 'stof_train_add_split2')
         else:
             g_x0 = self._add(gg, g6)
         if self.sgb and P:
