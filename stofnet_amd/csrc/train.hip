@@ -1198,6 +1198,166 @@ __global__ __launch_bounds__(256 * KH, 3 - KH) void conv_wgrad_split_async_kerne
     }
 }
 
+// The four-wave form on v_mfma_f32_16x16x32_f16 (K = 32 time rows per MFMA, four 16 x 16 accumulators per tap and wave): the shape
+// that holds the higher clock under the power cap (tools/micro/mfma_shape_lds.hip).  Same tiles, copies, swizzle and partials as
+// conv_wgrad_split_async_kernel<K, 1>; what differs is the operand addressing of the transposing reads (lane = (i = l & 15, q =
+// l >> 4): column i of the 16-column block of its M- / N-tile, rows 8 q .. 8 q + 7 of the 32-row K-step) and the accumulator layout.
+template <int K>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_async16_kernel(const WgradBatch b) {
+    constexpr int NW = 4, NT = 256, NBUF = 2;
+    extern __shared__ __attribute__((aligned(16))) char wa_lds[];
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = wave & 1, ni = wave >> 1;
+    const int layer = blockIdx.y, G = gridDim.x, gx = blockIdx.x;
+    const float* const X = b.x[layer];
+    const float* const DY = b.dy[layer];
+    const int L = b.L, pad = K >> 1;
+    static_assert(K - 1 <= 8, "the x part of a tile buffer holds 64 + 8 rows");
+    constexpr int NI = (WG_ROWS_H + WA_XROWS) / 4;
+    floatx4 acc[K][2][2];                                               // [tap][M-tile (o)][N-tile (c)]
+#pragma unroll
+    for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[d][m][n2][e] = 0.f;
+    float dbh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int i16 = lane & 15, q4 = lane >> 4;
+    const int rsel = i16 >> 2, csel = i16 & 3;                          // the lane's row and 8-byte chunk inside the 4 x 16 block it addresses
+    auto lane_off = [&](int m, int t2, int j) {                          // byte offset inside the row for swizzle (rsel + j) & 3, hi part
+        const int piece = 4 * m + 2 * t2 + (csel >> 1);
+        return ((piece ^ (((rsel + j) & 3) << 2)) << 4) + 8 * (csel & 1);
+    };
+    const int arow = (8 * q4 + rsel) * WA_ROWB;
+    // (tile t2 = 1 of an operand is piece + 2: offset ^ 32, the swizzle touching bits 6 and 7 only; lo part: ^ 128)
+    const int aoff0 = arow + lane_off(mi, 0, 0);
+    int boff0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff0[j] = WG_ROWS_H * WA_ROWB + arow + lane_off(ni, 0, j);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)wa_lds);
+    const int lrow = lane >> 4, slot = lane & 15;
+    auto issue = [&](int tile, int buf) {
+        const int n = tile / b.tiles_per_wf;
+        const int t0 = (tile - n * b.tiles_per_wf) * WG_ROWS_H;
+        const size_t wf = (size_t)n * L;
+#pragma unroll 1
+        for (int g = wave; g < NI; g += NW) {
+            const int R = 4 * g + lrow;
+            const bool isx = g >= WG_ROWS_H / 4;
+            int t = isx ? t0 - pad + (R - WG_ROWS_H) : t0 + R;
+            t = t < 0 ? 0 : (t > L - 1 ? L - 1 : t);
+            const int piece = slot ^ ((R & 3) << 2);
+            async_rows4((isx ? X : DY) + (wf + t) * 64 + 4 * piece, lds0 + buf * WA_BUF_BYTES + g * 4 * WA_ROWB);
+        }
+    };
+    auto frag = [&](const char* a) -> half8 {                            // rows r .. r + 3 and r + 4 .. r + 7 of the lane's column
+        const uint2 lo4 = tr_read(a), hi4 = tr_read(a + 4 * WA_ROWB);
+        union { uint4 u; half8 h; } c;
+        c.u = make_uint4(lo4.x, lo4.y, hi4.x, hi4.y);
+        return c.h;
+    };
+    int tile = gx;
+    if (tile < b.total_tiles) issue(tile, 0);
+    int buf = 0;
+    for (; tile < b.total_tiles; tile += G) {
+        wait_vm_lgkm0<0>();
+        __builtin_amdgcn_s_barrier();
+        if (tile + G < b.total_tiles) issue(tile + G, buf ^ 1);
+        char* const base = wa_lds + buf * WA_BUF_BYTES;
+        const int n = tile / b.tiles_per_wf;
+        const int t0 = (tile - n * b.tiles_per_wf) * WG_ROWS_H;
+        if (t0 - pad < 0 || t0 + WG_ROWS_H + pad > L) {
+            for (int i = tid; i < (WG_ROWS_H + WG_ROWS_H + K - 1) * 16; i += NT) {
+                const int R = i >> 4;
+                const int t = R >= WG_ROWS_H ? t0 - pad + (R - WG_ROWS_H) : t0 + R;
+                if (t < 0 || t >= L) *reinterpret_cast<float4*>(base + R * WA_ROWB + 16 * (i & 15)) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int u = 0; u < WG_ROWS_H / (NT / 16); ++u) {
+            const float4 v = *reinterpret_cast<const float4*>(base + ((tid >> 4) + (NT / 16) * u) * WA_ROWB + 16 * (tid & 15));
+            const unsigned w4[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const half2v hv = bits_h2w(w4[e]);
+                dbh[2 * e] += (float)hv[0];
+                dbh[2 * e + 1] += (float)hv[1];
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < WG_ROWS_H / 32; ++kk) {
+            half8 ah[2], al[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[m] = frag(base + (aoff0 ^ (32 * m)) + kk * 32 * WA_ROWB);
+                al[m] = frag(base + (aoff0 ^ (32 * m) ^ 128) + kk * 32 * WA_ROWB);
+            }
+            // the taps as a two-stage pipeline placed by hand: tap d + 1's operand reads are issued in front of tap d's MFMAs and the
+            // scheduling barrier keeps them there (left alone the compiler hoists several taps' reads and spills 25 registers)
+            half8 bh[2][2], bl[2][2];                                    // [stage][N-tile]
+            auto load_tap = [&](int st, int d) {
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    bh[st][n2] = frag(base + (boff0[d & 3] ^ (32 * n2)) + (kk * 32 + d) * WA_ROWB);
+                    bl[st][n2] = frag(base + (boff0[d & 3] ^ (32 * n2) ^ 128) + (kk * 32 + d) * WA_ROWB);
+                }
+            };
+            load_tap(0, 0);
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+                const int st = d & 1;
+                if (d + 1 < K) load_tap(st ^ 1, d + 1);
+                // part-major over the tap's four accumulators; per accumulator hi*hi, hi*lo, lo*hi as everywhere
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n2 = 0; n2 < 2; ++n2) acc[d][m][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[st][n2], acc[d][m][n2], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n2 = 0; n2 < 2; ++n2) acc[d][m][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[st][n2], acc[d][m][n2], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n2 = 0; n2 < 2; ++n2) acc[d][m][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[st][n2], acc[d][m][n2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        buf ^= 1;
+    }
+    // partial of the work-group: D element e of lane (column i16, q4) of tile (m, n2) = (o = 32 mi + 16 m + 4 q4 + e, c = 32 ni + 16 n2 + i16)
+    float* const part = b.part + ((size_t)layer * G + gx) * K * 64 * 64;
+#pragma unroll
+    for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    part[((size_t)d * 64 + 32 * mi + 16 * m + 4 * q4 + e) * 64 + 32 * ni + 16 * n2 + i16] = acc[d][m][n2][e];
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(wa_lds);
+    {
+        const int pc = (tid & 15) ^ (((tid >> 4) & 3) << 2);
+        float* const o = red + (tid >> 4) * 128 + (pc >> 3) * 64 + 8 * (pc & 7);
+        *reinterpret_cast<float4*>(o) = make_float4(dbh[0], dbh[1], dbh[2], dbh[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(dbh[4], dbh[5], dbh[6], dbh[7]);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < NT / 16; ++r) s += red[r * 128 + tid] + red[r * 128 + 64 + tid];
+        b.dbpart[((size_t)layer * G + gx) * 64 + tid] = s;
+    }
+}
+
 // orders a wave's LDS accesses for the compiler (the hardware executes one wave's LDS instructions in order)
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2049,10 +2209,11 @@ static int wgrad_batch_impl(const float* const* x, const float* const* dy, float
     if (G > tiles) G = (int)tiles;
     b.part = static_cast<float*>(workspace);
     const unsigned all = count >= 32 ? 0xffffffffu : ((1u << count) - 1u);
-    // STOF_TRAIN_WGRAD_ASYNC (read per call: tests switch it): unset / 1 = the four-wave global_load_lds kernel, 2 = its eight-wave
-    // form, 0 = the register-staged kernel
+    // STOF_TRAIN_WGRAD_ASYNC (read per call: tests switch it): unset / 3 = the four-wave global_load_lds kernel on 16x16x32 MFMAs
+    // (813 us on the box where the others were timed), 1 = the same on 32x32x16 (870), 2 = its eight-wave form (930), 0 = the
+    // register-staged kernel (884)
     const char* const aenv = getenv("STOF_TRAIN_WGRAD_ASYNC");
-    const int form = aenv ? atoi(aenv) : 1;
+    const int form = aenv ? atoi(aenv) : 3;
     if (form != 0 && K == 7 && (x_split & all) == all && (dy_split & all) == all && G >= 2 && (G & 1) == 0) {
         // every operand is split rows: the global_load_lds kernel, G / 2 work-groups of eight waves per layer, G partials as before
         b.dbpart = b.part + (size_t)count * G * K * 64 * 64;
@@ -2061,6 +2222,11 @@ static int wgrad_batch_impl(const float* const* x, const float* const* dy, float
             constexpr int lds_bytes = 3 * WA_BUF_BYTES;
             if (int st = once[0].ensure(reinterpret_cast<const void*>(&conv_wgrad_split_async_kernel<7, 2>), lds_bytes)) return st;
             hipLaunchKernelGGL((conv_wgrad_split_async_kernel<7, 2>), dim3((unsigned)(G / 2), (unsigned)count, 1), dim3(512), lds_bytes, s, b);
+        } else if (form == 3) {                                          // the four-wave form on 16x16x32 MFMAs
+            constexpr int lds_bytes = 2 * WA_BUF_BYTES;
+            static stof::LdsLimitOnce once16;
+            if (int st = once16.ensure(reinterpret_cast<const void*>(&conv_wgrad_split_async16_kernel<7>), lds_bytes)) return st;
+            hipLaunchKernelGGL((conv_wgrad_split_async16_kernel<7>), dim3((unsigned)G, (unsigned)count, 1), dim3(256), lds_bytes, s, b);
         } else {
             constexpr int lds_bytes = 2 * WA_BUF_BYTES;
             if (int st = once[1].ensure(reinterpret_cast<const void*>(&conv_wgrad_split_async_kernel<7, 1>), lds_bytes)) return st;

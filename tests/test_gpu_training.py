@@ -406,7 +406,7 @@ def test_training_step_at_benched_c5_shape_matches_reference(dev, precision):
 
 def test_weight_gradient_routes_agree(dev, monkeypatch):
     """r4: the backward pass has four routes to the eleven 64 -> 64 weight gradients -- split-row dumps + global_load_lds kernel
-    (default), its eight-wave form, split rows on the register-staged kernel, fp32 dumps -- and the first three feed the MFMAs the
+    (on 16x16x32 MFMAs: the default; on 32x32x16), its eight-wave form, split rows on the register-staged kernel, fp32 dumps -- and the first three feed the MFMAs the
     SAME fp16 hi / lo halves: the register-staged and the four-wave kernel sum them in the same order (bitwise equal weight
     gradients), the eight-wave form groups a tile's K-steps differently (1e-5); the fp32-dump route differs only in the leaky-ReLU
     mask of activations below 2^-25 and in the bias sums' order.  All of them against the reference golden."""
@@ -414,8 +414,8 @@ def test_weight_gradient_routes_agree(dev, monkeypatch):
     g = golden('f8_training_c5')
     frame = torch.from_numpy(synth.synth_echo(8, 2000, seed=3008)).to(dev)
     gt = torch.from_numpy(g['gt_true']).to(dev)
-    routes = {'async4': {}, 'async8': {'STOF_TRAIN_WGRAD_ASYNC': '2'}, 'split_regs': {'STOF_TRAIN_WGRAD_ASYNC': '0'},
-              'fp32_dumps': {'STOF_TRAIN_SPLIT_DUMPS': '0'}}
+    routes = {'async4': {'STOF_TRAIN_WGRAD_ASYNC': '1'}, 'async8': {'STOF_TRAIN_WGRAD_ASYNC': '2'}, 'async16': {'STOF_TRAIN_WGRAD_ASYNC': '3'},
+              'split_regs': {'STOF_TRAIN_WGRAD_ASYNC': '0'}, 'fp32_dumps': {'STOF_TRAIN_SPLIT_DUMPS': '0'}}
     got = {}
     for name, env in routes.items():
         for k in ('STOF_TRAIN_WGRAD_ASYNC', 'STOF_TRAIN_SPLIT_DUMPS'):
@@ -426,11 +426,11 @@ def test_weight_gradient_routes_agree(dev, monkeypatch):
         loss, pred = tr.forward_backward(frame, gt)
         got[name] = {n: tr.g[n].detach().clone() for n in tr.names}
         assert abs(float(loss) - float(g['loss'])) < 2e-6 * float(g['loss'])
-    for name in ('async8', 'split_regs'):
+    for name in ('async8', 'async16', 'split_regs'):
         for n in got['async4']:
             if n.endswith('.weight') and name == 'split_regs':     # same tiles per partial, same order inside a tile
                 assert torch.equal(got[name][n], got['async4'][n]), (name, n)
-            else:                                                  # async8 splits a tile's K-steps over two partials; bias sums differ in order
+            else:                                                  # async8 / async16 group a tile's K-steps differently; bias sums differ in order
                 assert float((got[name][n] - got['async4'][n]).abs().max()) <= 1e-5 * float(got['async4'][n].abs().max()) + 1e-12, (name, n)
     for n in got['async4']:
         gmax = float(g['gmax.' + n])
