@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void body_sweep_p2_kernel(const BodyParams 
     __syncthreads();
     // (waveforms of at least 2 S rows wrap at most once per offset: selects instead of loops -- the general loops compiled to
     // ~40 scalar instructions with a division per layer set-up)
-    const bool long_wf = Lp >= 2 * S;
+    constexpr bool long_wf = true;                // Lp >= 2 S: the host sends shorter waveforms to the r3 kernel (body_p2_rows_ok)
     auto decode_row = [&](int nB, int tB, int off, int& n, int& t) {
         n = nB;
         t = tB + off;

@@ -1626,6 +1626,9 @@ __global__ __launch_bounds__(256) void onsets_finalize_kernel(const OnsetPartial
 }
 
 constexpr int BODY_S = 192, BODY_RING = 256, BODY_RAWRING = 256;
+// The two-pass kernel takes (virtual) waveforms of at least 2 S stream rows: its row arithmetic wraps once per offset without loops
+// (the general loops cost the layer set-up ~100 scalar instructions and a division); shorter ones run on the r3 kernel.
+inline bool body_p2_rows_ok(int seg_len, int halo) { return seg_len + 2 * halo + GAP >= 2 * BODY_S; }
 constexpr int ONSET_MAX_SEGS = 32;       // seg_policy cuts a waveform into at most 2^5 segments
 
 // slots per waveform of the fused picker's partials for rows of L samples cut into nseg segments
@@ -1680,9 +1683,11 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
     const size_t body_p2_bytes = Lds16::BYTES + BODY_P2_C1F * sizeof(float);
     const size_t body_lds_bytes = body_p2 ? body_p2_bytes : body16 ? Lds16::BYTES : Lds::BYTES;
     static LdsLimitOnce body_lds, body16_lds, body_p2_lds, sgb_lds;     // one per template instantiation (PREC)
-    if (body_p2) {
+    if (body_p2) {                                   // (+ the r3 kernel: waveforms shorter than 2 S rows go to it, see body_p2_rows_ok)
         if (int st = body_p2_lds.ensure(reinterpret_cast<const void*>(&body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING>),
                                         (int)body_p2_bytes)) return st;
+        if (int st = body16_lds.ensure(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING, SHAPE_FAST>),
+                                       (int)Lds16::BYTES)) return st;
     } else if (body16) {
         if (int st = body16_lds.ensure(reinterpret_cast<const void*>(&body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING, SHAPE_FAST>),
                                        (int)Lds16::BYTES)) return st;
@@ -1780,12 +1785,12 @@ int launch_forward(const stof_net_desc* desc, const void* packed_dev, const floa
         int64_t wgs = nv < ncu ? nv : ncu;
         bp.wf_per_wg = (int)((nv + wgs - 1) / wgs);
         wgs = (nv + bp.wf_per_wg - 1) / bp.wf_per_wg;
-        if (body_p2)
+        if (body_p2 && body_p2_rows_ok(bp.seg_len, bp.halo))
             hipLaunchKernelGGL((body_sweep_p2_kernel<BODY_S, BODY_RING, BODY_RAWRING>), dim3((unsigned)wgs), dim3(256),
-                               body_lds_bytes, stream, bp);
+                               body_p2_bytes, stream, bp);
         else if (body16)
             hipLaunchKernelGGL((body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING, SHAPE_FAST>), dim3((unsigned)wgs), dim3(256),
-                               body_lds_bytes, stream, bp);
+                               Lds16::BYTES, stream, bp);
         else
             hipLaunchKernelGGL((body_sweep_kernel<PREC, BODY_S, BODY_RING, BODY_RAWRING>), dim3((unsigned)wgs), dim3(256),
                                body_lds_bytes, stream, bp);
@@ -2074,6 +2079,14 @@ static int train_sweep_impl(const stof_net_desc* desc, const void* blob_dev, con
 #endif
     int64_t wgs = 0;
     if (int st = train_sweep_geometry(desc, bp, N, L, &wgs)) return st;
+    if (p2 && !body_p2_rows_ok(bp.seg_len, bp.halo)) {            // short waveforms: the r3 kernel (fp32 dumps only)
+        if (split) return STOF_ERR_UNSUPPORTED;
+        auto k3 = &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, false>;
+        static LdsLimitOnce lds3;
+        if (int st = lds3.ensure(reinterpret_cast<const void*>(k3), (int)Lds16::BYTES)) return st;
+        hipLaunchKernelGGL(k3, dim3((unsigned)wgs), dim3(256), Lds16::BYTES, stream, bp);
+        return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+    }
     hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), lds_bytes, stream, bp);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
@@ -2215,6 +2228,14 @@ static int train_sweep_bwd_impl(const stof_net_desc* desc, const void* blob_dev,
 #endif
     int64_t wgs = 0;
     if (int st = train_sweep_geometry(desc, bp, N, L, &wgs)) return st;
+    if (p2 && !body_p2_rows_ok(bp.seg_len, bp.halo)) {            // short waveforms: the r3 kernel (fp32 dumps only)
+        if (split) return STOF_ERR_UNSUPPORTED;
+        auto k3 = &body_sweep_kernel<STOF_PREC_F16X3, BODY_S, BODY_RING, BODY_RAWRING, 16, true, true>;
+        static LdsLimitOnce lds3;
+        if (int st = lds3.ensure(reinterpret_cast<const void*>(k3), (int)Lds16::BYTES)) return st;
+        hipLaunchKernelGGL(k3, dim3((unsigned)wgs), dim3(256), Lds16::BYTES, stream, bp);
+        return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+    }
     hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(256), lds_bytes, stream, bp);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
