@@ -2214,7 +2214,7 @@ static int wgrad_batch_impl(const float* const* x, const float* const* dy, float
     // register-staged kernel (884)
     const char* const aenv = getenv("STOF_TRAIN_WGRAD_ASYNC");
     const int form = aenv ? atoi(aenv) : 3;
-    if (form != 0 && K == 7 && (x_split & all) == all && (dy_split & all) == all && G >= 2 && (G & 1) == 0) {
+    if (form != 0 && K == 7 && (x_split & all) == all && (dy_split & all) == all && (form != 2 || (G >= 2 && (G & 1) == 0))) {
         // every operand is split rows: the global_load_lds kernel, G / 2 work-groups of eight waves per layer, G partials as before
         b.dbpart = b.part + (size_t)count * G * K * 64 * 64;
         static stof::LdsLimitOnce once[2];
