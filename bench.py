@@ -473,7 +473,7 @@ def train_bench(args):
                            'sparse_sgb_backward_taken': sparse_sgb}
         out['final_loss'] = float(last['loss'])
         out['ranks'] = census
-        if not args.no_cpu_baseline:       # rank 0 only (the process group is already closed)
+        if not args.no_cpu_baseline and d.world == 1:       # rank 0 at N = 1 only (the process group is already closed)
             # the oracle's training step (torch autograd on the host cores), bounded sample
             from oracle import train_oracle
             cores = host_cores()
@@ -777,7 +777,7 @@ def infer_bench(args):
         out['whole_forward_tflops'] = round(total_flops(rows, L, R) * d.world * args.steps / dt / 1e12, 2)
         out['extras'] = extras
         out['ranks'] = census
-        if not args.no_cpu_baseline:       # rank 0 only (the process group is already closed)
+        if not args.no_cpu_baseline and d.world == 1:       # rank 0 at N = 1 only (the process group is already closed)
             srows = args.cpu_sample_rows or (256 if cfg != 'C4' else 128)
             srows = min(srows, rows)
             xs = x[:srows].cpu().numpy()
