@@ -93,14 +93,21 @@ def semi_global_block(x, p, prefix, scale, dtype, conv=conv1d_same, taps=None):
 
 
 def stofnet_forward(params: dict, x, upsample_factor: int = 4, semi_global_scale: int = 80,
-                    dtype=torch.float32, conv=conv1d_same, taps: dict | None = None):
+                    dtype=torch.float32, conv=conv1d_same, taps: dict | None = None, num_blocks: int | None = None):
     """models/stofnet.py:42-67.  `params` uses the reference's state_dict names.
     `taps`, if given, receives per-layer checkpoints (conv1 out, SGB out, each
-    residual state, conv12 out, conv_last out)."""
+    residual state, the second-last layer's out, conv_last out).  `num_blocks` (models/stofnet.py:11; default: read from
+    the parameter names) and the body kernel size (the weights' last dimension, padding='same') are general, as in the
+    reference's constructor; residual layers are models/stofnet.py:39's list."""
     p = params
     x = _t(x, dtype)
     W = lambda n: _t(p[n + '.weight'], dtype)
     B = lambda n: _t(p[n + '.bias'], dtype)
+    nb = num_blocks if num_blocks is not None else 1 + max(int(k[4:-7]) for k in p
+                                                             if k.startswith('conv') and k.endswith('.weight') and k[4:-7].isdigit())
+    if nb < 4:
+        raise ValueError('models/stofnet.py:60 reads the loop variable of :52: num_blocks < 4 fails in the reference')
+    residual_layers = list(range(3, nb - 1, 2)) + [nb - 1, nb]           # :39
     x = F.relu(conv(x, W('conv1'), B('conv1'), 4))                      # :45
     if taps is not None:
         taps['conv1'] = x
@@ -109,18 +116,20 @@ def stofnet_forward(params: dict, x, upsample_factor: int = 4, semi_global_scale
     if taps is not None:
         taps['x0'] = x
     res1 = res = x                                                        # :51
-    for i in range(2, 12):                                                # :52-58
-        y = conv(x, W(f'conv{i}'), B(f'conv{i}'), 3)
-        if i % 2:                       # i in {3,5,7,9,11}: residual add, no activation
+    for i in range(2, nb - 1):                                            # :52-58
+        w = W(f'conv{i}')
+        y = conv(x, w, B(f'conv{i}'), w.shape[-1] // 2)
+        if i in residual_layers:        # 13 blocks: i in {3,5,7,9,11}: residual add, no activation
             x = res + y
             res = x
             if taps is not None:
                 taps[f'res{i}'] = x
-        else:                           # i in {2,4,...,10}: leaky ReLU 0.01
+        else:                           # leaky ReLU 0.01
             x = F.leaky_relu(y, 0.01)
-    x = res1 + conv(x, W('conv12'), B('conv12'), 3)                       # :61-62
+    w = W(f'conv{nb - 1}')
+    x = res1 + conv(x, w, B(f'conv{nb - 1}'), w.shape[-1] // 2)           # :61-62
     if taps is not None:
-        taps['conv12'] = x
+        taps[f'conv{nb - 1}'] = x
     x = conv(x, W('conv_last'), B('conv_last'), 1)                        # :65
     if taps is not None:
         taps['conv_last'] = x

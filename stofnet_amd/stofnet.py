@@ -116,14 +116,20 @@ class StofNet(nn.Module):
 
     # ---- kernel-side state -------------------------------------------------
     def _supported(self):
-        return (self.num_features == 64 and self.num_blocks == 13 and list(self.kernel_sizes) == [9, 7, 3]
+        """models/stofnet.py:11 takes any geometry; the gfx950 kernels take any `num_blocks` >= 4 (fewer fail in the
+        reference too: its :60 reads the loop variable of :52) and body kernel sizes 1 / 3 / 5 / 7, with 64 features, one
+        input channel, a 9-tap first and a 3-tap last layer (their paddings 4 and 1 are fixed at :23-24)."""
+        ks = list(self.kernel_sizes)
+        return (self.num_features == 64 and self.num_blocks >= 4 and len(ks) == 3 and ks[0] == 9 and ks[2] == 3
+                and ks[1] in (1, 3, 5, 7)
                 and self.in_channels == 1 and (self.semi_global_scale == 1 or 2 <= self.semi_global_scale <= 256)
                 and 1 <= self.upsample_factor <= 64)
 
     def _fused_sweep(self):
-        """The persistent LDS-resident sweep serves the shipped geometry (no SemiGlobalBlock, or sample_scale 80); any
-        other semi_global_scale runs layer by layer on the channel-last MFMA kernels of the training path."""
-        return self.semi_global_scale in (1, 80)
+        """The persistent LDS-resident sweep serves the shipped geometry (13 blocks, 7-tap body, no SemiGlobalBlock or
+        sample_scale 80); any other semi_global_scale / num_blocks / body kernel size runs layer by layer on the
+        channel-last MFMA kernels of the training path."""
+        return self.semi_global_scale in (1, 80) and self.num_blocks == 13 and list(self.kernel_sizes) == [9, 7, 3]
 
     def _param_list(self):
         ps = [self.conv1.weight, self.conv1.bias]
@@ -165,8 +171,8 @@ class StofNet(nn.Module):
     # ---- forward -------------------------------------------------------------
     def forward(self, x, _events=None):
         if not self._supported():
-            raise NotImplementedError('only the shipped StofNet layout (64 features, 13 blocks, kernels [9,7,3], 1 input '
-                                      'channel; semi_global_scale 1 or 2..256) has gfx950 kernels')
+            raise NotImplementedError('the gfx950 kernels take 64 features, 1 input channel, kernel_sizes [9, 1|3|5|7, 3], '
+                                      'num_blocks >= 4, semi_global_scale 1 or 2..256')
         _lib.require_device(x, 'x')
         if x.dim() != 3 or x.shape[1] != self.in_channels:
             raise RuntimeError(f'expected input [N, {self.in_channels}, L], got {list(x.shape)}')
@@ -221,11 +227,13 @@ class StofNet(nn.Module):
         key = (str(dev), precision)
         if key not in self._engines:
             self._engines[key] = TrainEngine(dev, self.upsample_factor, self.semi_global_block is not None, precision,
-                                             scale=self.semi_global_scale if self.semi_global_block is not None else 80)
+                                             scale=self.semi_global_scale if self.semi_global_block is not None else 80,
+                                             num_blocks=self.num_blocks, body_kernel=list(self.kernel_sizes)[1])
         return self._engines[key]
 
     def _forward_layerwise(self, x):
-        """Inference for a semi_global_scale other than 80 (models/stofnet.py:11 accepts any): every layer on the
+        """Inference for a semi_global_scale other than 80, a num_blocks other than 13 or a body kernel other than 7
+        (models/stofnet.py:11 accepts any): every layer on the
         channel-last MFMA kernels, activations dropped as soon as the next layer has consumed them.  'auto' maps to the
         exact fp32 mode here (the range guard lives in the fused sweep)."""
         if x.shape[0] == 0:

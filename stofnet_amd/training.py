@@ -35,18 +35,27 @@ class TrainEngine:
     kernels + AdamW kernel on one flat buffer) and by the autograd boundary of `StofNet.forward` in train mode
     (`StofNetFunction`: torch computes the loss and owns the optimizer, as in the reference's main.py:221-248)."""
 
-    def __init__(self, dev, r, sgb, precision='fp32', scale=80):
+    def __init__(self, dev, r, sgb, precision='fp32', scale=80, num_blocks=13, body_kernel=7):
         if precision not in ('fp32', 'f16x3'):
             raise ValueError("precision must be 'fp32' or 'f16x3'")
         self.prec = 1 if precision == 'f16x3' else 0       # arithmetic of every 64/512-channel convolution: forward, data gradient, weight gradient
         self.dev, self.r, self.sgb = dev, int(r), bool(sgb)
+        # models/stofnet.py:11: any num_blocks >= 4 (the reference's forward reads the loop variable of :52 at :60) and any odd
+        # body kernel the layer kernels take; the fused sweeps serve the shipped 13 x k7 geometry, everything else runs
+        # layer by layer on the channel-last MFMA kernels
+        self.nb, self.kb = int(num_blocks), int(body_kernel)
+        if self.nb < 4:
+            raise NotImplementedError('StofNet: num_blocks < 4 fails in the reference (models/stofnet.py:60)')
+        if self.kb not in (1, 3, 5, 7):
+            raise NotImplementedError('StofNet: the gfx950 layer kernels take body kernel sizes 1, 3, 5, 7')
         # SemiGlobalBlock geometry (models/stofnet.py:83-85): pool / upsample by `scale`, feat_scale = max(1, scale // 10)
         self.scale = int(scale)
         self.cmid = 64 * max(1, self.scale // 10)
         # split-fp16 mode: conv2..conv12 + conv_last of the forward run as ONE fused sweep that also writes every layer's
         # output for the backward pass (stof_train_sweep) instead of twelve layer launches; STOF_TRAIN_SWEEP=0 keeps the layers
         import os
-        self.sweep = (self.prec == 1 and (not self.sgb or self.scale == 80) and os.environ.get('STOF_TRAIN_SWEEP', '1') != '0'
+        self.sweep = (self.prec == 1 and (not self.sgb or self.scale == 80) and self.nb == 13 and self.kb == 7
+                      and os.environ.get('STOF_TRAIN_SWEEP', '1') != '0'
                       and os.environ.get('STOF_BODY16', '1') != '0')
         self._sweep_blob = None
         # SemiGlobalBlock backward from the pool's sparse gradient (STOF_TRAIN_SGB_SPARSE=0: dense route, for A/B runs and tests)
@@ -173,7 +182,10 @@ class TrainEngine:
             t = dump[:12 * n * L * 64].view(12, n, L, 64)
             xs = [t[0]] + [t[2 + 2 * k] for k in range(5)]
             ys = [t[1 + 2 * k] for k in range(5)]
-            saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=t[11], bwd=bwd, n=n, L=L, P=P, rem=rem,
+            v = {1: xs[0]}
+            for k in range(5):
+                v[2 * k + 2], v[2 * k + 3] = ys[k], xs[k + 1]
+            saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, v=v, x6=t[11], bwd=bwd, n=n, L=L, P=P, rem=rem,
                          _dump=dump, split=split, desc=desc, wdev=[p[f'conv{i}.weight'] for i in range(2, 13)],
                          wc=p.get(sg + 'contract_conv.weight'), wl=p['conv_last.weight'], w1=p['conv1.weight'])
             return z, saved
@@ -185,19 +197,26 @@ class TrainEngine:
         if not keep:
             del c, pooled, arg, e
             c = pooled = arg = e = None
-        xs, ys = [x0], []
-        for k in range(5):
-            ys.append(self._conv(xs[-1], fwd[f'conv{2 * k + 2}'], p[f'conv{2 * k + 2}.bias'], 64, 64, 7, ACT_LRELU))
-            xs.append(self._conv(ys[-1], fwd[f'conv{2 * k + 3}'], p[f'conv{2 * k + 3}.bias'], 64, 64, 7, ACT_NONE, residual=xs[-1]))
-            if not keep:
-                ys[-1] = None
-                if k > 0:
-                    xs[k] = None
-        x6 = self._conv(xs[5], fwd['conv12'], p['conv12.bias'], 64, 64, 7, ACT_NONE, residual=x0)
+        # models/stofnet.py:51-62 for any num_blocks: even layers leaky ReLU, odd layers (>= 3) add the running residual
+        # and become it; the second-last layer adds res1 = x0.  v[i] = output of conv{i} (v[1] = x0).
+        nb, kb = self.nb, self.kb
+        v = {1: x0}
+        for i in range(2, nb - 1):
+            nm = f'conv{i}'
+            if i % 2:
+                v[i] = self._conv(v[i - 1], fwd[nm], p[nm + '.bias'], 64, 64, kb, ACT_NONE, residual=v[i - 2])
+                if not keep:                   # v[i] is the running residual now; x0 stays for the long skip
+                    v[i - 1] = None
+                    if i > 3:
+                        v[i - 2] = None
+            else:
+                v[i] = self._conv(v[i - 1], fwd[nm], p[nm + '.bias'], 64, 64, kb, ACT_LRELU)
+        nm = f'conv{nb - 1}'
+        x6 = self._conv(v[nb - 2], fwd[nm], p[nm + '.bias'], 64, 64, kb, ACT_NONE, residual=x0)
         z = self._conv(x6, fwd['conv_last'], p['conv_last.bias'], 64, r, 3, ACT_NONE)      # [N, L, r] == shuffled [N, L*r]
         if not keep:
             return z.view(n, L * r), None
-        saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, xs=xs, ys=ys, x6=x6, bwd=bwd, n=n, L=L, P=P, rem=rem,
+        saved = dict(x=x, a1=a1, c=c, pooled=pooled, arg=arg, e=e, v=v, x6=x6, bwd=bwd, n=n, L=L, P=P, rem=rem,
                      wc=p.get('semi_global_block.contract_conv.weight'), wl=p['conv_last.weight'], w1=p['conv1.weight'])
         return z.view(n, L * r), saved
 
@@ -237,7 +256,9 @@ class TrainEngine:
         r, st = self.r, self._st()
         sg = 'semi_global_block.'
         n, L, P, rem = saved['n'], saved['L'], saved['P'], saved['rem']
-        xs, ys, x6, bwd, a1 = saved['xs'], saved['ys'], saved['x6'], saved['bwd'], saved['a1']
+        xs, ys, v, x6, bwd, a1 = saved.get('xs'), saved.get('ys'), saved['v'], saved['x6'], saved['bwd'], saved['a1']
+        nb, kb = self.nb, self.kb
+        second_last = f'conv{nb - 1}'
         self._gscale = float(gscale)
         self.g = g
         dz = dpred.view(n, L, r)
@@ -256,13 +277,13 @@ class TrainEngine:
                 _lib.check(lib.stof_train_to_split_rows(_lib.ptr(g6f), _lib.ptr(g6), n * L, st), 'stof_train_to_split_rows')
         else:
             _lib.check(code, 'stof_train_conv_last_dgrad')
-        batch_wgrad = (self.prec == 1 and saved.get('_dump') is not None and 'conv12' not in bwd
+        batch_wgrad = (self.prec == 1 and saved.get('_dump') is not None and second_last not in bwd
                        and (split or os.environ.get('STOF_TRAIN_WGRAD_BATCH', '1') != '0'))
         if split and not batch_wgrad:
             raise RuntimeError('split-row dumps without the backward sweep')
         if not batch_wgrad:
-            self._wgrad(xs[5], g6, 'conv12', 64, 64, 7)
-        if saved.get('_dump') is not None and 'conv12' not in bwd:
+            self._wgrad(v[nb - 2], g6, second_last, 64, 64, kb)
+        if saved.get('_dump') is not None and second_last not in bwd:
             # the eleven data-gradient convolutions conv12^T .. conv2^T as ONE backward sweep (stof_train_sweep_bwd), then the
             # weight gradients from its dumps: tensor j odd = dL/dx_k, k = (11 - j) / 2; j even = dL/d(pre-activation of conv(12 - j))
             import ctypes
@@ -308,13 +329,23 @@ class TrainEngine:
                     self._wgrad(a, d, nm, 64, 64, 7)
             gg = T[11]                                                                   # dL/dx_0 without the long skip
         else:
-            gg = self._conv(g6, bwd['conv12'], None, 64, 64, 7)                       # d/dx5
-            for k in range(4, -1, -1):
-                nb, na = f'conv{2 * k + 3}', f'conv{2 * k + 2}'
-                self._wgrad(ys[k], gg, nb, 64, 64, 7)
-                u = self._conv(gg, bwd[nb], None, 64, 64, 7, ACT_LRELU, saved=ys[k])  # d/d(pre-activation of conv_a)
-                self._wgrad(xs[k], u, na, 64, 64, 7)
-                gg = self._conv(u, bwd[na], None, 64, 64, 7, residual=gg)             # d/dx_k
+            # any num_blocks, layer by layer.  Walking down from the second-last layer: an odd layer i holds the TOTAL gradient
+            # gg of its output (its own consumer + the residual add two layers on); its transposed convolution, masked with
+            # lrelu'(v[i-1]), is u = the gradient before the activation of the even layer i-1; that layer's transposed
+            # convolution plus gg (the residual path) is the total gradient of v[i-2].
+            m = nb - 2                                                                # last layer of the loop (:52)
+            if m % 2:
+                gg, u = self._conv(g6, bwd[second_last], None, 64, 64, kb), None        # d/dv[m], v[m] a residual state
+            else:
+                gg, u = None, self._conv(g6, bwd[second_last], None, 64, 64, kb, ACT_LRELU, saved=v[m])
+            for i in range(m, 1, -1):
+                nm = f'conv{i}'
+                if i % 2:
+                    self._wgrad(v[i - 1], gg, nm, 64, 64, kb)
+                    u = self._conv(gg, bwd[nm], None, 64, 64, kb, ACT_LRELU, saved=v[i - 1])
+                else:
+                    self._wgrad(v[i - 1], u, nm, 64, 64, kb)
+                    gg = self._conv(u, bwd[nm], None, 64, 64, kb, residual=gg)      # (gg None for the loop's last layer)
         if split:                                                                 # long skip res1 (models/stofnet.py:62)
             g_x0 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
             _lib.check(lib.stof_train_add_split2(_lib.ptr(gg), _lib.ptr(g6), _lib.ptr(g_x0), n * L, st), 'stof_train_add_split2')
@@ -458,12 +489,13 @@ class StofNetTrainer(TrainEngine):
     def __init__(self, model: StofNet, lr=5e-4, weight_decay=1e-8, lambda_value=1e-2, mask_amplitude=20,
                  kernel_size=7, sigma=1, betas=(0.9, 0.999), eps=1e-8, process_group=None, precision='f16x3'):
         if not model._supported():
-            raise NotImplementedError('only the shipped StofNet architecture is supported')
+            raise NotImplementedError('this StofNet geometry has no gfx950 kernels (see StofNet._supported)')
         if kernel_size != 7:
             raise NotImplementedError('the loss kernel implements the 7-tap blur of config.yaml:23')
         params = list(model.named_parameters())
         super().__init__(params[0][1].device, model.upsample_factor, model.semi_global_block is not None, precision,
-                         scale=model.semi_global_scale if model.semi_global_block is not None else 80)
+                         scale=model.semi_global_scale if model.semi_global_block is not None else 80,
+                         num_blocks=model.num_blocks, body_kernel=list(model.kernel_sizes)[1])
         self.model = model
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
         self.lam, self.amp = float(lambda_value), float(mask_amplitude)
