@@ -185,6 +185,13 @@ int stof_hilbert(const float* x, int64_t N, int64_t n, float* env, float* re, fl
 int stof_hilbert_streamed(const float* x, int64_t N, int64_t n, float* env, float* re, float* im,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* float64 rows: utils/hilbert.py:11 (torch.fft.fft) follows the input's dtype, so a float64 frame gives a complex128
+ * analytic signal.  Same outputs in double; any n (mixed-radix plan over n's prime factors, O(n log n) for smooth n).
+ * workspace: stof_hilbert_f64_workspace_bytes(N, n) bytes of device memory.                                       */
+size_t stof_hilbert_f64_workspace_bytes(int64_t N, int64_t n);
+int stof_hilbert_f64(const double* x, int64_t N, int64_t n, double* env, double* re, double* im,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * GradPeak (models/gradpeak.py).  Common arguments:
  *   grad_step, taps[2*radius+1], radius : gradient spacing g and the Gaussian taps for sigma = (2g-1)/6, prepared

@@ -74,6 +74,9 @@ _SIGNATURES = {
     'stof_hilbert_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int64]),
     'stof_hilbert': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                 _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    'stof_hilbert_f64_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int64]),
+    'stof_hilbert_f64': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                    _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     'stof_hilbert_streamed': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                          _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     'stof_gradpeak_moments': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32,

@@ -834,3 +834,129 @@ int hilbert_impl(const float* x, int64_t N, int64_t n, float* env, float* re, fl
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 }  // namespace
+
+// ----------------------------------------------------------------------------------------------------------------
+// float64 rows (utils/hilbert.py:5-21 keeps a float64 input in complex128: torch.fft.fft follows the input's dtype).
+// Not a tuned path -- no configuration of the reference feeds float64 -- but the same O(n log n) transform for any n:
+// one work-group per row walks a mixed-radix Stockham autosort plan (decimation in frequency; radices = the prime
+// factors of n, 4 where two 2s pair up) between two global scratch rows, twiddles from a table e^{-2 pi i j / n}
+// built in double with sincospi (exact argument reduction: j / n is formed once, no accumulated angles).
+//   stage (radix R, current length c = R m, stride s, c s = n):  out[q + s (R p + k)] = W_c^{p k} sum_r in[q + s (p + r m)] W_R^{r k}
+//   (p < m, k < R, q < s); W_c^{p k} = tw[p k s] (p k s < n), W_R^{r k} = tw[((r k) mod R) n / R].
+// The inverse runs the same plan on the conjugated, filtered spectrum (ifft(F) = conj(fft(conj(F))) / n).
+// ----------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int F64_MAX_FACTORS = 32, F64_GRID = 512, F64_THREADS = 256;
+struct F64Plan { int nf; int radix[F64_MAX_FACTORS]; };
+
+__global__ void hilbert_f64_twiddle_kernel(double2* tw, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double sn, cs;
+    sincospi(2.0 * (double)j / (double)n, &sn, &cs);
+    tw[j] = make_double2(cs, -sn);
+}
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// one forward transform of the row held in `a` (natural order); returns the buffer that holds the result
+__device__ double2* f64_forward(double2* a, double2* b, const double2* __restrict__ tw, const int n, const F64Plan& plan) {
+    int c = n, s = 1;
+    for (int f = 0; f < plan.nf; ++f) {
+        const int R = plan.radix[f], m = c / R, step = n / R;
+        for (int o = threadIdx.x; o < n; o += blockDim.x) {
+            const int q = o % s, t = o / s, k = t % R, p = t / R;
+            const double2* src = a + q + (long long)s * p;
+            double2 acc = src[0];
+            int rk = 0;                                                     // (r k) mod R
+            for (int r = 1; r < R; ++r) {
+                rk += k;
+                if (rk >= R) rk -= R;
+                const double2 v = src[(long long)s * m * r], w = tw[(long long)rk * step];
+                acc.x += v.x * w.x - v.y * w.y;
+                acc.y += v.x * w.y + v.y * w.x;
+            }
+            b[o] = cmul(acc, tw[(long long)p * k * s]);
+        }
+        __syncthreads();
+        double2* const tmp = a; a = b; b = tmp;
+        c = m; s *= R;
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(F64_THREADS) void hilbert_f64_kernel(const double* __restrict__ x, const long long N, const int n,
+                                                                    double* env, double* re, double* im,
+                                                                    const double2* __restrict__ tw, double2* scratch, const F64Plan plan) {
+    double2* const bufA = scratch + (long long)blockIdx.x * 2 * n;
+    double2* const bufB = bufA + n;
+    const int half = n / 2;
+    const double inv_n = 1.0 / (double)n;
+    for (long long row = blockIdx.x; row < N; row += gridDim.x) {
+        const double* xr = x + row * n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) bufA[i] = make_double2(xr[i], 0.0);
+        __syncthreads();
+        double2* f = f64_forward(bufA, bufB, tw, n, plan);
+        double2* other = f == bufA ? bufB : bufA;
+        // utils/hilbert.py:13-17: bins above n // 2 zeroed, bins 1 .. n // 2 - 1 doubled (bin n // 2 kept as it is, also for
+        // odd n: Q6); conjugated for the inverse
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+            const double h = k > half ? 0.0 : ((k >= 1 && k < half) ? 2.0 : 1.0);
+            const double2 v = f[k];
+            f[k] = make_double2(h * v.x, -h * v.y);
+        }
+        __syncthreads();
+        const double2* v = f64_forward(f, other, tw, n, plan);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const double a = v[i].x * inv_n, b = -v[i].y * inv_n;
+            if (re) re[row * n + i] = a;
+            if (im) im[row * n + i] = b;
+            if (env) env[row * n + i] = hypot(a, b);
+        }
+        __syncthreads();
+    }
+}
+
+bool f64_plan(int64_t n, F64Plan* plan) {
+    plan->nf = 0;
+    int twos = 0;
+    while (n % 2 == 0) { ++twos; n /= 2; }
+    for (; twos >= 2; twos -= 2) plan->radix[plan->nf++] = 4;
+    if (twos) plan->radix[plan->nf++] = 2;
+    for (int64_t d = 3; d * d <= n; d += 2)
+        while (n % d == 0) {
+            if (plan->nf >= F64_MAX_FACTORS) return false;
+            plan->radix[plan->nf++] = (int)d;
+            n /= d;
+        }
+    if (n > 1) {
+        if (plan->nf >= F64_MAX_FACTORS) return false;
+        plan->radix[plan->nf++] = (int)n;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" size_t stof_hilbert_f64_workspace_bytes(int64_t N, int64_t n) {
+    if (n <= 0 || N <= 0) return 0;
+    const int64_t grid = N < F64_GRID ? N : F64_GRID;
+    return (size_t)n * sizeof(double2) * (1 + 2 * (size_t)grid) + 256;
+}
+
+extern "C" int stof_hilbert_f64(const double* x, int64_t N, int64_t n, double* env, double* re, double* im,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+    if (N < 0 || n < 0) return STOF_ERR_BAD_ARG;
+    if (N == 0 || n == 0) return STOF_OK;
+    if (!x || (!env && !re && !im)) return STOF_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < stof_hilbert_f64_workspace_bytes(N, n)) return STOF_ERR_WORKSPACE;
+    if (n > (1 << 22)) return STOF_ERR_UNSUPPORTED;
+    F64Plan plan;
+    if (!f64_plan(n, &plan)) return STOF_ERR_UNSUPPORTED;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    double2* const tw = reinterpret_cast<double2*>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
+    double2* const scratch = tw + n;
+    const int grid = (int)(N < F64_GRID ? N : F64_GRID);
+    hipLaunchKernelGGL(hilbert_f64_twiddle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, (int)n);
+    hipLaunchKernelGGL(hilbert_f64_kernel, dim3(grid), dim3(F64_THREADS), 0, stream, x, (long long)N, (int)n, env, re, im, tw, scratch, plan);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}

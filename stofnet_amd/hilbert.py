@@ -10,8 +10,19 @@ def _run(y: torch.Tensor, want_env: bool, want_complex: bool, keep_cached: bool 
     _lib.require_device(y, 'y')
     n = y.shape[-1]
     rows = y.numel() // max(n, 1)
-    yc = y.detach().contiguous().float().reshape(rows, n)
     lib = _lib.lib()
+    if y.dtype == torch.float64:
+        # utils/hilbert.py:11: torch.fft.fft follows the input's dtype -- a float64 frame stays in complex128
+        yc = y.detach().contiguous().reshape(rows, n)
+        ws = torch.empty(max(lib.stof_hilbert_f64_workspace_bytes(rows, n), 16), dtype=torch.uint8, device=y.device)
+        env = torch.empty_like(yc) if want_env else None
+        re = torch.empty_like(yc) if want_complex else None
+        im = torch.empty_like(yc) if want_complex else None
+        with torch.cuda.device(y.device):
+            _lib.check(lib.stof_hilbert_f64(_lib.ptr(yc), rows, n, _lib.ptr(env), _lib.ptr(re), _lib.ptr(im),
+                                            _lib.ptr(ws), ws.numel(), _lib.stream_ptr(y.device)), 'stof_hilbert_f64')
+        return env, re, im
+    yc = y.detach().contiguous().float().reshape(rows, n)
     ws = torch.empty(max(lib.stof_hilbert_workspace_bytes(rows, n), 16), dtype=torch.uint8, device=y.device)
     env = torch.empty_like(yc) if want_env else None
     re = torch.empty_like(yc) if want_complex else None
@@ -24,7 +35,8 @@ def _run(y: torch.Tensor, want_env: bool, want_complex: bool, keep_cached: bool 
 
 
 def hilbert_transform(y):
-    """Analytic signal (complex64) along the last dim, with the reference's bin rule (Q6)."""
+    """Analytic signal along the last dim, with the reference's bin rule (Q6): complex128 for a float64 input,
+    complex64 otherwise (torch.fft.fft's dtype rule, utils/hilbert.py:11)."""
     _, re, im = _run(y, False, True)
     return torch.complex(re, im).reshape(y.shape)
 

@@ -491,6 +491,32 @@ def test_hilbert_compile_time_plan_lengths(dev, n, rows):
         assert np.abs(hilbert_envelope(shifted).cpu().numpy() - env).max() < ENV_TOL
 
 
+@pytest.mark.parametrize('n', [1, 2, 7, 16, 250, 2000, 2001])
+def test_hilbert_float64_golden(dev, n):
+    """utils/hilbert.py:11: a float64 input stays in complex128 (torch.fft.fft's dtype rule); reference golden f15."""
+    from stofnet_amd import hilbert_transform, HilbertTransform
+    g = golden('f15_hilbert_f64')
+    x = torch.from_numpy(g[f'x_n{n}']).to(dev)
+    v = hilbert_transform(x)
+    assert v.dtype == torch.complex128 and v.shape == x.shape
+    scale = max(1.0, float(np.abs(g[f'x_n{n}']).max()))
+    assert np.abs(v.real.cpu().numpy() - g[f're_n{n}']).max() < 1e-12 * scale
+    assert np.abs(v.imag.cpu().numpy() - g[f'im_n{n}']).max() < 1e-12 * scale
+    env = HilbertTransform()(x[:, None, :])
+    assert env.dtype == torch.float64
+    assert np.abs(env[:, 0].cpu().numpy() - np.hypot(g[f're_n{n}'], g[f'im_n{n}'])).max() < 1e-12 * scale
+
+
+@pytest.mark.parametrize('rows,n', [(1, 3), (5, 31), (2, 97), (3, 1999), (700, 1536), (4, 4096), (2, 10007), (3, 20000), (2, 30720)])
+def test_hilbert_float64_more_lengths_vs_oracle(dev, rows, n):
+    """Any n (prime lengths run as one O(n^2) stage), more rows than the persistent grid (700 > 512), long rows."""
+    from stofnet_amd import hilbert_transform
+    x = np.random.RandomState(n).standard_normal((rows, n))
+    v = hilbert_transform(torch.from_numpy(x).to(dev)).cpu().numpy()
+    want = po.hilbert_transform(x)
+    assert np.abs(v - want).max() < 1e-11
+
+
 def test_hilbert_module_concat(dev):
     from stofnet_amd import HilbertTransform
     g = golden('f5_hilbert')
