@@ -63,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument('--rows', type=int, default=0, help='override the rows per GPU of the chosen config (smoke runs)')
     ap.add_argument('--cpu-sample-rows', type=int, default=0,
                     help='rows of the bounded CPU-oracle sample (default: 256; C4 128; the extra configs of the default run use 32)')
+    ap.add_argument('--train-graph', action='store_true',
+                    help='C5, fused trainer, one GPU: replay the step from its hipGraph (StofNetTrainer.train_step_graphed) instead of '
+                         'launching kernel by kernel; measured equal (r4: 0.805 vs 0.799 ms at batch 4, 4.05 vs 4.04 ms at batch 256)')
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='default run (C2, one GPU): do not measure C3 / C4 / C5 afterwards (extras.configs)')
     ap.add_argument('--dry-run', action='store_true',
@@ -417,8 +420,11 @@ def train_bench(args):
     gt = torch.from_numpy(np.sort(rng.integers(1, L * R, size=(nb, 1, 2)), -1)).to(d.dev)
     last = {}
 
+    # --train-graph: one hipGraph per step shape (forward + loss + backward + range guard; AdamW behind it): the same kernels
+    graphed = args.trainer == 'fused' and d.world == 1 and args.train_graph
+
     def step(_s):
-        last['loss'], _ = tr.train_step(x, gt)
+        last['loss'], _ = (tr.train_step_graphed if graphed else tr.train_step)(x, gt)
 
     if args.trainer == 'autograd':
         import torch.nn.functional as F
@@ -456,7 +462,7 @@ def train_bench(args):
                         d.world * nb * args.steps / dt, dt, DTYPE_TEXT[args.train_precision],
                         f'C5 training step [{nb},1,{L}] -> [{nb},1,{L * R}] per GPU, Gaussian-mask loss, AdamW, upsample_factor={R}',
                         {'rows_per_gpu': nb, 'L': L, 'upsample_factor': R, 'precision': args.train_precision,
-                         'trainer': args.trainer,
+                         'trainer': args.trainer, 'hip_graph': bool(graphed),
                          'parallelism': f'ddp{d.world}: one flat 2.58 MB gradient all-reduce per step'})
         # `achieved` counts the ALGORITHMIC flops of the step (what the reference's dense autograd does).  Since r3 the two backward
         # passes of the SemiGlobalBlock's contract convolution (22.6 % of that count) work on the max-pool's sparse gradient and are

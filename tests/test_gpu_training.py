@@ -591,3 +591,37 @@ def test_twenty_step_loss_curve_follows_the_reference(dev, tp):
     tr.raise_if_overflow()
     rel = np.abs(np.array(got) - want) / np.abs(want)
     assert rel.max() < 1e-4, (tp, rel.max(), int(rel.argmax()), got[:3], want[:3].tolist())
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
+@pytest.mark.parametrize('n,L', [(4, 2000), (3, 400)])
+def test_graphed_training_step_equals_the_launched_one(dev, precision, n, L):
+    """`train_step_graphed` replays forward + loss + backward (+ range guard) from one hipGraph: same kernels, same order, so
+    four steps on changing batches leave bit-identical predictions, weights and optimizer state (losses to 1e-12); a second shape gets its own graph;
+    an overflow still reaches `raise_if_overflow()` through the captured guard."""
+    r, sgs = 10, 80
+    _, m_a, tr_a = make(dev, r, sgs, precision=precision)
+    _, m_b, tr_b = make(dev, r, sgs, precision=precision)
+    rng = np.random.default_rng(5)
+    for it in range(4):
+        x = torch.from_numpy(synth.synth_echo(n, L, seed=40 + it)).to(dev)
+        gt = torch.from_numpy(np.sort(rng.integers(1, L * r, size=(n, 1, 2)), -1)).to(dev)
+        la, pa = tr_a.train_step(x, gt)
+        lb, pb = tr_b.train_step_graphed(x, gt)
+        assert abs(float(la) - float(lb)) <= 1e-12 * abs(float(la)), it      # (the loss sum is a float64 atomic: last-ulp order effects)
+        assert torch.equal(pa, pb)
+        assert torch.equal(tr_a.flat, tr_b.flat) and torch.equal(tr_a.exp_avg_sq, tr_b.exp_avg_sq), it
+    assert len(tr_b._step_graphs) == 1
+    x2 = torch.from_numpy(synth.synth_echo(2, 320, seed=9)).to(dev)
+    gt2 = torch.tensor([[[300, 900]], [[700, 0]]], dtype=torch.int64, device=dev)
+    la, _ = tr_a.train_step(x2, gt2)
+    lb, _ = tr_b.train_step_graphed(x2, gt2)
+    assert abs(float(la) - float(lb)) <= 1e-12 * abs(float(la)) and len(tr_b._step_graphs) == 2 and torch.equal(tr_a.flat, tr_b.flat)
+    tr_b.raise_if_overflow()
+    if precision == 'f16x3':
+        big = torch.full((2, 1, 320), 3.0e6, device=dev)
+        before = tr_b.flat.clone()
+        tr_b.train_step_graphed(big, gt2)
+        with pytest.raises(FloatingPointError):
+            tr_b.raise_if_overflow()
+        assert torch.isfinite(tr_b.flat).all() and (tr_b.flat - before).abs().max() < 1e-2      # the step was a no-op but for weight decay
