@@ -365,6 +365,9 @@ int stof_train_sgb_contract_pool(const float* conv1_w, const float* conv1_b, con
                                  void* blob_dev, const float* x, float* pooled, uint8_t* arg, int64_t N, int64_t L, void* stream);
 int stof_train_upsample_add(const float* a, const float* e, float* out, int64_t N, int64_t L, int64_t P,
                             int32_t rem_half, int32_t scale, void* stream);
+/* The same for rows of C channels (any C >= 1): the standalone SemiGlobalBlock (models/stofnet.py:80) takes any width. */
+int stof_train_upsample_add_c(const float* a, const float* e, float* out, int64_t N, int64_t L, int64_t P,
+                              int32_t rem_half, int32_t scale, int32_t C, void* stream);
 int stof_train_upsample_bwd(const float* g, const float* e, float* ge, int64_t N, int64_t L, int64_t P,
                             int32_t rem_half, int32_t scale, void* stream);
 /* Training forward on the fused sweep (split-fp16 mode; main.py:221 with the model in train mode): conv2 .. conv12 +

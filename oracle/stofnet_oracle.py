@@ -70,16 +70,15 @@ def semi_global_block(x, p, prefix, scale, dtype, conv=conv1d_same, taps=None):
     L = x.shape[-1]
     npool = L // scale
     rem = L - npool * scale
-    z = F.leaky_relu(conv(x, _t(p[prefix + 'contract_conv.weight'], dtype),
-                          _t(p[prefix + 'contract_conv.bias'], dtype), 2), 0.01)
+    wc, we = _t(p[prefix + 'contract_conv.weight'], dtype), _t(p[prefix + 'expand_conv.weight'], dtype)
+    z = F.leaky_relu(conv(x, wc, _t(p[prefix + 'contract_conv.bias'], dtype), wc.shape[-1] // 2), 0.01)     # :88 padding = k // 2
     if taps is not None:
         taps['sgb_contract'] = z
     # max-pool, floor mode: the tail remainder is dropped (models/stofnet.py:103)
     z = z[..., :npool * scale].reshape(z.shape[0], z.shape[1], npool, scale).amax(-1)
     if taps is not None:
         taps['sgb_pooled'] = z
-    z = F.leaky_relu(conv(z, _t(p[prefix + 'expand_conv.weight'], dtype),
-                          _t(p[prefix + 'expand_conv.bias'], dtype), 2), 0.01)
+    z = F.leaky_relu(conv(z, we, _t(p[prefix + 'expand_conv.bias'], dtype), we.shape[-1] // 2), 0.01)
     if taps is not None:
         taps['sgb_expand'] = z
     if rem % 2:

@@ -131,6 +131,7 @@ _SIGNATURES = {
     'stof_train_sgb_blob_bytes': (_c.c_size_t, []),
     'stof_train_sgb_contract_pool': (_c.c_int, [_c.c_void_p] * 8 + [_c.c_int64, _c.c_int64, _c.c_void_p]),
     'stof_train_upsample_add': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_void_p]),
+    'stof_train_upsample_add_c': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_void_p]),
     'stof_train_upsample_bwd': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_void_p]),
     'stof_train_loss': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'stof_train_loss_target': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p]),

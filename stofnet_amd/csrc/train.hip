@@ -1830,6 +1830,19 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restri
     *reinterpret_cast<float4*>(out + nt * 64 + 4 * q) = v;
 }
 
+// the same for rows of C channels (any C): the standalone SemiGlobalBlock of models/stofnet.py:80 takes any width
+__global__ __launch_bounds__(256) void upsample_add_c_kernel(const float* __restrict__ a, const float* __restrict__ e,
+                                                             float* __restrict__ out, long long total, int L, int P, int rem_half, int S, int C) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= total) return;
+    const int ch = (int)(i % C);
+    const long long nt = i / C;
+    const int pos = (int)(nt % L) - rem_half;
+    float v = a[i];
+    if (pos >= 0 && pos < S * P) v += e[((nt / L) * P + pos / S) * C + ch];
+    out[i] = v;
+}
+
 // ge[n][w][ch] = lrelu'(e) * sum_{t in window w} g[n][t][ch]
 // One wave per (n, w): lane = (row subset part = lane >> 4, channel quad c4 = lane & 15); a lane adds the rows k = part mod 4
 // of the window with 16-byte loads, the four subsets are combined in a fixed order.  (One thread per channel walking the 80
@@ -2456,6 +2469,18 @@ extern "C" int stof_train_upsample_add(const float* a, const float* e, float* ou
     if (!a || !out || (!e && P > 0)) return STOF_ERR_BAD_ARG;
     hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks_for(N * L * 16)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        a, e, out, (int)N, (int)L, (int)P, rem_half, scale);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_upsample_add_c(const float* a, const float* e, float* out, int64_t N, int64_t L, int64_t P,
+                                         int32_t rem_half, int32_t scale, int32_t C, void* stream) {
+    if (N < 0 || L < 0 || P < 0 || C < 1 || scale < 1 || rem_half < 0 || rem_half + P * scale > L) return STOF_ERR_BAD_ARG;
+    if (N * L == 0) return STOF_OK;
+    if (!a || !out || (!e && P > 0)) return STOF_ERR_BAD_ARG;
+    if (L > 0x7fffffffLL || P * scale > 0x7fffffffLL) return STOF_ERR_UNSUPPORTED;
+    const long long total = (long long)N * L * C;
+    hipLaunchKernelGGL(upsample_add_c_kernel, dim3(blocks_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       a, e, out, total, (int)L, (int)P, rem_half, scale, C);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

@@ -56,15 +56,17 @@ class SemiGlobalBlock(nn.Module):
         """models/stofnet.py:98-117 standalone: x [N, C, L] -> x + pad(upsample(lrelu(expand(maxpool(lrelu(contract(x))))))).
         Inside StofNet the block is fused into the network kernels; this entry serves direct callers on the same
         channel-last MFMA convolution, pooling and upsample-add kernels the training path uses (exact fp32).  The NCL <->
-        channel-last transposes at the boundary are torch copies.  C = in_channels = out_channels = 64 (the kernels'
-        row width); no autograd graph."""
+        channel-last transposes at the boundary are torch copies.  Any C = in_channels = out_channels (the add at :115
+        needs them equal), any odd kernel size up to 9, sample_scale 2..256; no autograd graph."""
         from .training import TrainEngine
         _lib.require_device(x, 'x')
         cin = self.contract_conv.in_channels
         if x.dim() != 3 or x.shape[1] != cin:
             raise RuntimeError(f'expected input [N, {cin}, L], got {list(x.shape)}')
-        if cin != 64 or self.expand_conv.out_channels != 64 or self.contract_conv.kernel_size[0] != 5:
-            raise NotImplementedError('SemiGlobalBlock.forward: the gfx950 kernels serve 64 -> 64 channels, kernel size 5')
+        K = int(self.contract_conv.kernel_size[0])
+        if self.expand_conv.out_channels != cin or K % 2 == 0 or K > 9:
+            raise NotImplementedError('SemiGlobalBlock.forward: the gfx950 kernels serve in_channels == out_channels and odd '
+                                      'kernel sizes up to 9')
         n, _, L = x.shape
         S = int(self.sample_scale)
         if L // S == 0:
@@ -76,7 +78,8 @@ class SemiGlobalBlock(nn.Module):
         with torch.cuda.device(x.device):
             a = x.detach().float().permute(0, 2, 1).contiguous()
             out = eng._sgb_forward(a, eng._repack(self.contract_conv.weight.detach(), False), self.contract_conv.bias.detach(),
-                                   eng._repack(self.expand_conv.weight.detach(), False), self.expand_conv.bias.detach())[0]
+                                   eng._repack(self.expand_conv.weight.detach(), False), self.expand_conv.bias.detach(),
+                                   width=cin, K=K)[0]
             return out.permute(0, 2, 1).contiguous()
 
 

@@ -220,20 +220,22 @@ class TrainEngine:
                      wc=p.get('semi_global_block.contract_conv.weight'), wl=p['conv_last.weight'], w1=p['conv1.weight'])
         return z.view(n, L * r), saved
 
-    def _sgb_head(self, a1, w_contract, b_contract, w_expand, b_expand):
-        """contract conv -> lrelu -> max-pool -> expand conv -> lrelu (models/stofnet.py:100-107) on channel-last a1."""
+    def _sgb_head(self, a1, w_contract, b_contract, w_expand, b_expand, width=64, K=5):
+        """contract conv -> lrelu -> max-pool -> expand conv -> lrelu (models/stofnet.py:100-107) on channel-last a1
+        [N, L, width]; inside StofNet width = 64 and K = 5, the standalone block (models/stofnet.py:80) takes any."""
         lib, st = _lib.lib(), self._st()
         n, L = a1.shape[0], a1.shape[1]
-        S, cm = self.scale, self.cmid
+        S = self.scale
+        cm = self.cmid if width == 64 else width * max(1, S // 10)
         P = L // S
-        c = self._conv(a1, w_contract, b_contract, 64, cm, 5, ACT_LRELU)
+        c = self._conv(a1, w_contract, b_contract, width, cm, K, ACT_LRELU)
         pooled = torch.empty((n, max(P, 1), cm), dtype=torch.float32, device=self.dev)[:, :P]
         arg = torch.empty((n, max(P, 1), cm), dtype=torch.uint8, device=self.dev)[:, :P]
         _lib.check(lib.stof_train_pool(_lib.ptr(c), _lib.ptr(pooled), _lib.ptr(arg), n, L, P, cm, S, st), 'stof_train_pool')
-        e = self._conv(pooled, w_expand, b_expand, cm, 64, 5, ACT_LRELU)
+        e = self._conv(pooled, w_expand, b_expand, cm, width, K, ACT_LRELU)
         return c, pooled, arg, e
 
-    def _sgb_forward(self, a1, w_contract, b_contract, w_expand, b_expand):
+    def _sgb_forward(self, a1, w_contract, b_contract, w_expand, b_expand, width=64, K=5):
         """SemiGlobalBlock.forward (models/stofnet.py:98-117) on channel-last a1 [N, L, 64]:
         a1 + pad(upsample(lrelu(expand(maxpool(lrelu(contract(a1))))))).  Returns (out, c, pooled, arg, e)."""
         lib, st = _lib.lib(), self._st()
@@ -241,10 +243,14 @@ class TrainEngine:
         S = self.scale
         P = L // S
         rem = L - S * P
-        c, pooled, arg, e = self._sgb_head(a1, w_contract, b_contract, w_expand, b_expand)
+        c, pooled, arg, e = self._sgb_head(a1, w_contract, b_contract, w_expand, b_expand, width, K)
         out = torch.empty_like(a1)
-        _lib.check(lib.stof_train_upsample_add(_lib.ptr(a1), _lib.ptr(e), _lib.ptr(out), n, L, P, rem // 2, S, st),
-                   'stof_train_upsample_add')
+        if width == 64:
+            _lib.check(lib.stof_train_upsample_add(_lib.ptr(a1), _lib.ptr(e), _lib.ptr(out), n, L, P, rem // 2, S, st),
+                       'stof_train_upsample_add')
+        else:
+            _lib.check(lib.stof_train_upsample_add_c(_lib.ptr(a1), _lib.ptr(e), _lib.ptr(out), n, L, P, rem // 2, S, width, st),
+                       'stof_train_upsample_add_c')
         return out, c, pooled, arg, e
 
     def _backward_saved(self, saved, dpred, g, gscale, dx=None):

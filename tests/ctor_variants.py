@@ -50,3 +50,17 @@ def variant_input(N: int, L: int, seed: int):
 def variant_cotangent(N: int, M: int, seed: int):
     """dL/dy for the gradient check: loss = sum(y * t)."""
     return np.random.RandomState(seed + 1000).standard_normal((N, 1, M)).astype(np.float32)
+
+
+# standalone SemiGlobalBlock(in_channels, out_channels, sample_scale, kernel_size) variants (models/stofnet.py:80-117): L, seed
+SGB_VARIANTS = {
+    'c32_s20_k3': dict(ctor=(32, 32, 20, 3), N=2, L=244),       # remainder 4: the up-sampled map is shifted by 2 (Q2)
+    'c96_s5_k7': dict(ctor=(96, 96, 5, 7), N=2, L=200),         # feat_scale = max(1, 5 // 10) = 1
+    'c64_s30_k9': dict(ctor=(64, 64, 30, 9), N=1, L=300),       # 192 contracted channels, the widest kernel the layer kernels take
+    'c8_s40_k5': dict(ctor=(8, 8, 40, 5), N=3, L=160),          # rows narrower than one 64-channel block
+    'c1_s2_k1': dict(ctor=(1, 1, 2, 1), N=2, L=64),
+}
+
+
+def sgb_input(N, C, L, seed):
+    return np.random.RandomState(seed).standard_normal((N, C, L)).astype(np.float32)

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import golden
-from ctor_variants import VARIANTS, variant_params, variant_input, variant_cotangent
+from ctor_variants import VARIANTS, SGB_VARIANTS, sgb_input, variant_params, variant_input, variant_cotangent
 from oracle import stofnet_oracle as so
 
 
@@ -98,3 +98,34 @@ def test_gpu_gradients_match_reference_autograd(name, tp, tol):
     assert all(p.grad is not None for p in named.values())
     for n, gr in grads_ref.items():
         assert rel(named[n].grad.cpu().numpy(), gr) < tol, n
+
+
+def _sgb_case(name):
+    from stofnet_amd.stofnet import SemiGlobalBlock
+    var, g = SGB_VARIANTS[name], golden('f16_sgb_variants')
+    seed = int(g[f'{name}.seed'])
+    blk = SemiGlobalBlock(*var['ctor'])
+    params = variant_params({n: tuple(t.shape) for n, t in blk.state_dict().items()}, seed)
+    return var, blk, params, sgb_input(var['N'], var['ctor'][0], var['L'], seed), g[f'{name}.y']
+
+
+@pytest.mark.parametrize('name', list(SGB_VARIANTS))
+def test_oracle_semi_global_block_variants_match_reference(name):
+    var, blk, params, x, y_ref = _sgb_case(name)
+    y = so.semi_global_block(torch.from_numpy(x), params, '', var['ctor'][2], torch.float32)
+    assert rel(y.numpy(), y_ref) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', list(SGB_VARIANTS))
+def test_gpu_semi_global_block_variants_match_reference(name):
+    """SemiGlobalBlock(in, out, sample_scale, kernel_size).forward standalone (models/stofnet.py:98-117) for other widths,
+    scales and kernel sizes: channel-last MFMA convolutions + pool + generic-width upsample-add, exact-fp32 mode."""
+    var, blk, params, x, y_ref = _sgb_case(name)
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    blk = blk.to('cuda:0')
+    y = blk(torch.from_numpy(x).to('cuda:0'))
+    assert y.shape == y_ref.shape
+    assert rel(y.cpu().numpy(), y_ref) < 1e-5
+    with pytest.raises(RuntimeError):              # odd remainder (Q1) / fewer samples than a window, as in the reference
+        blk(torch.from_numpy(x[..., :var['ctor'][2] + 1 if var['ctor'][2] > 2 else 1]).to('cuda:0'))
