@@ -435,6 +435,14 @@ int stof_train_add(const float* a, const float* b, float* out, int64_t n, void* 
 /* torch.optim.AdamW step on one flat parameter vector (main.py:179,248).                             */
 int stof_train_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+/* The same step behind the range guard of the split-fp16 training arithmetic (the reference trains in plain fp32,
+ * main.py:221-248): one scan of the gradient bucket (and of *loss, if given) for non-finite values, then AdamW -- if the scan
+ * found one, the gradients count as zero (and are zeroed) and guard_words[1] is raised (sticky; the caller reads and clears
+ * it whenever it likes).  guard_words: two device ints owned by the caller, zero before the first step; guard_words[0] is
+ * scratch (the number of the last bad step).  Two launches, no host read.                                              */
+int stof_train_adamw_guarded(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int64_t step, const double* loss,
+                             int32_t* guard_words, void* stream);
 
 #ifdef __cplusplus
 }

@@ -146,6 +146,7 @@ _SIGNATURES = {
     'stof_train_wgrad_batch_split': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_uint32, _c.c_uint32, _c.c_int64,
                                                 _c.c_int64, _c.c_int32, _c.c_float, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     'stof_train_adamw': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_int64, _c.c_void_p]),
+    'stof_train_adamw_guarded': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -1948,13 +1948,24 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
 }
 
 // torch.optim.AdamW step (decoupled weight decay), one flat parameter vector
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// GUARD (split-fp16 training range guard): word[0] == epoch says grad_guard_kernel found a non-finite gradient or loss in THIS
+// step -- the gradients then count as zero (and are zeroed), as if the step's backward had produced none, and the sticky flag
+// word[1] is raised for the next host read (StofNetTrainer.raise_if_overflow)
+template <bool GUARD>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long long n, float lr, float beta1, float beta2,
-                                                    float eps, float wd, float bc1, float bc2_sqrt) {
+                                                    float eps, float wd, float bc1, float bc2_sqrt, int* word, int epoch) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= n) return;
     float pv = p[i];
-    const float gv = g[i];
+    float gv = g[i];
+    if (GUARD) {
+        if (*reinterpret_cast<volatile int*>(word) == epoch) {
+            gv = 0.f;
+            g[i] = 0.f;
+            if (i == 0) atomicOr(word + 1, 1);
+        }
+    }
     pv *= 1.f - lr * wd;
     const float mv = beta1 * m[i] + (1.f - beta1) * gv;
     const float vv = beta2 * v[i] + (1.f - beta2) * gv * gv;
@@ -1962,6 +1973,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     v[i] = vv;
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
     p[i] = pv - (lr / bc1) * (mv / denom);
+}
+
+// any non-finite gradient (exponent all ones) or loss in this step -> word[0] = epoch (epochs only grow: nothing to clear)
+__global__ __launch_bounds__(256) void grad_guard_kernel(const float* __restrict__ g, long long n, const double* __restrict__ loss,
+                                                         int* word, int epoch) {
+    bool bad = false;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        bad |= (__float_as_uint(g[i]) & 0x7f800000u) == 0x7f800000u;
+    if (loss && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(*loss);
+        bad |= (u & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicMax(word, epoch);
 }
 
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -2540,8 +2564,25 @@ extern "C" int stof_train_adamw(float* params, const float* grads, float* exp_av
     if (!params || !grads || !exp_avg || !exp_avg_sq) return STOF_ERR_BAD_ARG;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), params, grads,
-                       exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+    hipLaunchKernelGGL(adamw_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), params,
+                       const_cast<float*>(grads), exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                       (float)sqrt(bc2), static_cast<int*>(nullptr), 0);
+    return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
+}
+
+extern "C" int stof_train_adamw_guarded(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                        float beta1, float beta2, float eps, float weight_decay, int64_t step, const double* loss,
+                                        int32_t* guard_words, void* stream) {
+    if (n < 0 || step < 1 || step > 0x7fffffffLL) return STOF_ERR_BAD_ARG;
+    if (n == 0) return STOF_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !guard_words) return STOF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const unsigned scan_blocks = blocks_for(n) < 1024u ? blocks_for(n) : 1024u;
+    hipLaunchKernelGGL(grad_guard_kernel, dim3(scan_blocks), dim3(256), 0, s, grads, (long long)n, loss, guard_words, (int)step);
+    hipLaunchKernelGGL(adamw_kernel<true>, dim3(blocks_for(n)), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long long)n, lr,
+                       beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), guard_words, (int)step);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
 

@@ -507,7 +507,10 @@ class StofNetTrainer(TrainEngine):
         self.lam, self.amp = float(lambda_value), float(mask_amplitude)
         self.group = process_group
         self.target_max_hook = None      # tests: stands in for the MAX all-reduce of the blurred-target maximum
-        self.overflow_flag = None        # sticky device word of the split-fp16 range guard (_guard_grads)
+        # range guard of the split-fp16 arithmetic: two device ints ([0] number of the last bad step, [1] sticky flag),
+        # written by stof_train_adamw_guarded, read by raise_if_overflow()
+        self._guard_words = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        self._guard_pending = None       # set by _guard_grads: the next step() runs behind the guard (with this loss)
         self.step_count = 0
         dev = self.dev
         _lib.require_device(params[0][1], 'model parameters')
@@ -583,33 +586,42 @@ class StofNetTrainer(TrainEngine):
     def _guard_grads(self, loss=None):
         """Range guard of the split-fp16 training arithmetic (the reference trains in plain fp32): an activation or a
         back-propagated value beyond the fp16 range turns into inf / NaN and would reach every weight through AdamW.  On the
-        device, without a host read: if the loss or any gradient is non-finite the whole gradient bucket is zeroed (this step
-        becomes a no-op for the weights apart from weight decay) and a sticky flag is set; `raise_if_overflow()` reads it."""
-        ok = torch.isfinite(self.flat_grad).all()
-        if loss is not None:
-            ok = ok & torch.isfinite(loss).all()
-        self.flat_grad.copy_(torch.where(ok, self.flat_grad, torch.zeros((), dtype=torch.float32, device=self.dev)))
-        bad = (~ok).to(torch.int32).reshape(1)
-        if self.overflow_flag is None:
-            self.overflow_flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.overflow_flag.copy_(torch.maximum(self.overflow_flag, bad))      # (in place: the word is part of a captured graph)
+        device, without a host read: the next `step()` scans the gradient bucket (and `loss`) for non-finite values in front
+        of AdamW (stof_train_adamw_guarded: two launches; r4, first form: a dozen torch element-wise launches, ~90 us of a
+        4 ms step); if it finds one the gradients count as zero (this step becomes a no-op for the weights apart from weight
+        decay) and a sticky flag is set; `raise_if_overflow()` reads it."""
+        self._guard_pending = (loss,)
+
+    @property
+    def overflow_flag(self):
+        return self._guard_words[1:2]
 
     def raise_if_overflow(self):
         """One host read: raises FloatingPointError if any step since the last check left the fp16 range (its update was
         skipped); use precision='fp32' for such data."""
-        if self.overflow_flag is not None and int(self.overflow_flag.item()) != 0:
-            self.overflow_flag.zero_()
+        if int(self._guard_words[1].item()) != 0:
+            self._guard_words[1:2].zero_()
             raise FloatingPointError(f"StofNetTrainer(precision='{'f16x3' if self.prec == 1 else 'fp32'}'): a loss or gradient was "
                                      "non-finite (fp16 range overflow of the split-fp16 arithmetic); those steps were skipped -- "
                                      "train with precision='fp32'")
 
     def step(self):
         self.step_count += 1
+        pending, self._guard_pending = self._guard_pending, None
         with torch.cuda.device(self.dev):
-            _lib.check(_lib.lib().stof_train_adamw(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
-                                                   _lib.ptr(self.exp_avg_sq), self.flat.numel(), self.lr, self.betas[0],
-                                                   self.betas[1], self.eps, self.wd, self.step_count, self._st()),
-                       'stof_train_adamw')
+            if pending is not None:
+                loss = pending[0]
+                if loss is not None and (loss.dtype != torch.float64 or loss.device != self.flat.device):
+                    loss = loss.detach().to(self.flat.device, torch.float64)
+                _lib.check(_lib.lib().stof_train_adamw_guarded(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
+                                                               _lib.ptr(self.exp_avg_sq), self.flat.numel(), self.lr, self.betas[0],
+                                                               self.betas[1], self.eps, self.wd, self.step_count, _lib.ptr(loss),
+                                                               _lib.ptr(self._guard_words), self._st()), 'stof_train_adamw_guarded')
+            else:
+                _lib.check(_lib.lib().stof_train_adamw(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
+                                                       _lib.ptr(self.exp_avg_sq), self.flat.numel(), self.lr, self.betas[0],
+                                                       self.betas[1], self.eps, self.wd, self.step_count, self._st()),
+                           'stof_train_adamw')
         self.model._packed = {}                                # inference weights must be repacked
 
     def train_step(self, frame, gt_true):
@@ -622,11 +634,11 @@ class StofNetTrainer(TrainEngine):
         return loss, pred
 
     def train_step_graphed(self, frame, gt_true):
-        """`train_step` with forward + loss + backward (+ the split-fp16 range guard) replayed from ONE hipGraph per
+        """`train_step` with forward + loss + backward replayed from ONE hipGraph per
         (frame shape, gt shape): the step is ~65 kernel launches, and at the reference's own batch size (config.yaml:11:
         4 waveforms) the launches, not the kernels, set its duration.  The first call for a shape runs two eager passes
         on a side stream (lazy workspaces, LDS limits and device queries happen there) and captures; later calls copy
-        `frame` / `gt_true` into the graph's input buffers and replay.  AdamW stays an ordinary launch behind the graph
+        `frame` / `gt_true` into the graph's input buffers and replay.  The range guard + AdamW stay ordinary launches behind the graph
         (its bias correction takes the step count, and `lr` may change per epoch: host scalars).  The returned loss and
         prediction are the graph's output buffers: the next call overwrites them.  With a process group of more than one
         rank (collectives between the kernels) this is `train_step`."""
@@ -640,8 +652,6 @@ class StofNetTrainer(TrainEngine):
             if hit is None:
                 sf = frame.detach().to(self.dev, torch.float32).clone()
                 sg = gt_true.detach().to(self.dev, torch.int64).clone()
-                if self.overflow_flag is None:
-                    self.overflow_flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
                 side = torch.cuda.Stream(self.dev)
                 side.wait_stream(torch.cuda.current_stream(self.dev))
                 with torch.cuda.stream(side):
@@ -651,13 +661,13 @@ class StofNetTrainer(TrainEngine):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     loss, pred = self.forward_backward(sf, sg)
-                    if self.prec == 1:
-                        self._guard_grads(loss)
                 hit = graphs[key] = (graph, sf, sg, loss, pred)
             graph, sf, sg, loss, pred = hit
             sf.copy_(frame.detach().reshape(sf.shape))
             sg.copy_(gt_true.detach().reshape(sg.shape))
             graph.replay()
+        if self.prec == 1:
+            self._guard_grads(loss)            # (the guard's scan takes the step number, a host scalar: it runs behind the graph)
         self.step()
         return loss, pred
 

@@ -625,3 +625,52 @@ def test_graphed_training_step_equals_the_launched_one(dev, precision, n, L):
         with pytest.raises(FloatingPointError):
             tr_b.raise_if_overflow()
         assert torch.isfinite(tr_b.flat).all() and (tr_b.flat - before).abs().max() < 1e-2      # the step was a no-op but for weight decay
+
+
+def test_guarded_adamw_kernel_pair(dev):
+    """stof_train_adamw_guarded: a scan of the gradient bucket (+ the loss) in front of AdamW, on the device.  Finite step ==
+    stof_train_adamw bit for bit; a NaN / inf anywhere in the gradients, or a non-finite loss, turns the step into one with zero
+    gradients (moments decay, weight decay applies), zeroes the bucket and raises the sticky word; the next finite step is a
+    normal one again (the bad-step word holds the step NUMBER: nothing to clear)."""
+    import ctypes
+    from stofnet_amd import _lib
+    lib = _lib.lib()
+    st = _lib.stream_ptr(dev)
+    n = 100_003
+    g = torch.Generator().manual_seed(2)
+    p0 = torch.randn(n, generator=g).to(dev)
+    grads = [torch.randn(n, generator=g).to(dev) * 1e-2 for _ in range(4)]
+    words = torch.zeros(2, dtype=torch.int32, device=dev)
+    hyper = (1e-3, 0.9, 0.999, 1e-8, 1e-2)
+
+    def run(guarded, bad_at=None, bad_loss=None):
+        p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        words.zero_()
+        flags = []
+        for step, gr in enumerate(grads, 1):
+            gr = gr.clone()
+            loss = torch.tensor([0.5], dtype=torch.float64, device=dev)
+            if bad_at == step:
+                gr[n // 2 + 7] = float('nan')
+                gr[3] = float('inf')
+            if bad_loss == step:
+                loss[0] = float('inf')
+            if guarded:
+                _lib.check(lib.stof_train_adamw_guarded(_lib.ptr(p), _lib.ptr(gr), _lib.ptr(m), _lib.ptr(v), n, *hyper, step,
+                                                        _lib.ptr(loss), _lib.ptr(words), st), 'guarded')
+                flags.append((int(words[1]), float(gr.abs().max())))
+                words[1:2].zero_()
+            else:
+                if bad_at == step or bad_loss == step:
+                    gr.zero_()
+                _lib.check(lib.stof_train_adamw(_lib.ptr(p), _lib.ptr(gr), _lib.ptr(m), _lib.ptr(v), n, *hyper, step, st), 'plain')
+        return p, m, v, flags
+
+    for kw in ({}, {'bad_at': 2}, {'bad_loss': 3}, {'bad_at': 1}, {'bad_at': 4, 'bad_loss': 4}):
+        pa, ma, va, flags = run(True, **kw)
+        pb, mb, vb, _ = run(False, **kw)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), kw
+        bad_step = kw.get('bad_at') or kw.get('bad_loss')
+        for step, (flag, gmax) in enumerate(flags, 1):
+            assert flag == (1 if step == bad_step else 0), (kw, step)
+            assert (gmax == 0.0) == (step == bad_step), (kw, step)
