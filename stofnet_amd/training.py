@@ -29,6 +29,24 @@ def gaussian_kernel(size, sigma=1.0):
     return k / np.sum(k)
 
 
+class _LazyRepack(dict):
+    """name -> kernel-layout image of a weight, packed on first use: which images a step needs depends on the route its
+    kernels take (the fused SemiGlobalBlock forward packs its own, the sparse backward and conv_last's data-gradient kernel
+    read the raw weights) -- in the default C5 step three of five images were packed and never read.  Keys are known up
+    front (`name in images` decides the backward route)."""
+
+    def __init__(self, engine, weights, flip):
+        super().__init__()
+        self._engine, self._weights, self._flip = engine, weights, flip
+
+    def __contains__(self, k):
+        return k in self._weights
+
+    def __missing__(self, k):
+        img = self[k] = self._engine._repack(self._weights[k], self._flip)
+        return img
+
+
 class TrainEngine:
     """Layer-by-layer forward with saved activations and the full backward pass of StofNet on the gfx950 training
     kernels (`stof_train_*`), on explicit parameter / gradient dictionaries.  Shared by `StofNetTrainer` (fused loss
@@ -122,11 +140,11 @@ class TrainEngine:
         st = self._st()
         use_sweep = self.sweep and 'conv2.weight' in p
         head = ('semi_global_block.',) if use_sweep else ('conv', 'semi_global_block.')        # layers that still run one by one
-        fwd = {k[:-7]: self._repack(v, False) for k, v in p.items()
-               if k.endswith('.weight') and k != 'conv1.weight' and k.startswith(head)}
+        fwd = _LazyRepack(self, {k[:-7]: w for k, w in p.items()
+                                 if k.endswith('.weight') and k != 'conv1.weight' and k.startswith(head)}, False)
         sweep_bwd = use_sweep and os.environ.get('STOF_TRAIN_SWEEP_BWD', '1') != '0'       # conv2..conv12 data gradients: one sweep too
-        bwd = {k[:-7]: self._repack(v, True) for k, v in p.items() if k.endswith('.weight') and k != 'conv1.weight'
-               and not (sweep_bwd and k[:-7] in BODY_CONVS)} if keep else None
+        bwd = _LazyRepack(self, {k[:-7]: w for k, w in p.items() if k.endswith('.weight') and k != 'conv1.weight'
+                                 and not (sweep_bwd and k[:-7] in BODY_CONVS)}, True) if keep else None
         a1 = torch.empty((n, L, 64), dtype=torch.float32, device=self.dev)
         _lib.check(lib.stof_train_conv1(_lib.ptr(x), _lib.ptr(p['conv1.weight']), _lib.ptr(p['conv1.bias']), _lib.ptr(a1),
                                         n, L, st), 'stof_train_conv1')
