@@ -887,8 +887,11 @@ __device__ double2* f64_forward(double2* a, double2* b, const double2* __restric
 
 __global__ __launch_bounds__(F64_THREADS) void hilbert_f64_kernel(const double* __restrict__ x, const long long N, const int n,
                                                                     double* env, double* re, double* im,
-                                                                    const double2* __restrict__ tw, double2* scratch, const F64Plan plan) {
-    double2* const bufA = scratch + (long long)blockIdx.x * 2 * n;
+                                                                    const double2* __restrict__ tw, double2* scratch, const F64Plan plan,
+                                                                    const int use_lds) {
+    // rows of up to LDS_BYTES / 32 samples (5,120) keep both buffers in LDS (flat addressing: the same code walks either)
+    extern __shared__ __attribute__((aligned(16))) unsigned char f64_rows[];
+    double2* const bufA = use_lds ? reinterpret_cast<double2*>(f64_rows) : scratch + (long long)blockIdx.x * 2 * n;
     double2* const bufB = bufA + n;
     const int half = n / 2;
     const double inv_n = 1.0 / (double)n;
@@ -956,7 +959,14 @@ extern "C" int stof_hilbert_f64(const double* x, int64_t N, int64_t n, double* e
     double2* const tw = reinterpret_cast<double2*>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
     double2* const scratch = tw + n;
     const int grid = (int)(N < F64_GRID ? N : F64_GRID);
+    const size_t lds = (size_t)2 * n * sizeof(double2);
+    const int use_lds = lds <= (size_t)LDS_BYTES ? 1 : 0;
+    if (use_lds) {
+        static stof::LdsLimitOnce f64_once;
+        if (int st = f64_once.ensure(reinterpret_cast<const void*>(&hilbert_f64_kernel), LDS_BYTES)) return st;
+    }
     hipLaunchKernelGGL(hilbert_f64_twiddle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, (int)n);
-    hipLaunchKernelGGL(hilbert_f64_kernel, dim3(grid), dim3(F64_THREADS), 0, stream, x, (long long)N, (int)n, env, re, im, tw, scratch, plan);
+    hipLaunchKernelGGL(hilbert_f64_kernel, dim3(grid), dim3(F64_THREADS), use_lds ? lds : 0, stream, x, (long long)N, (int)n, env, re, im, tw,
+                       scratch, plan, use_lds);
     return hipGetLastError() == hipSuccess ? STOF_OK : STOF_ERR_HIP;
 }
